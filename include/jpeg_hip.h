@@ -1,0 +1,165 @@
+/*
+ * jpeg_hip.h -- C ABI of the MI355X (gfx950) JPEG encode path.
+ *
+ * The reference (uriGrif/jpeg-encoder) has no FFI of its own: its API is the
+ * five `JpegImage` methods that `main` calls in order (src/main.rs:17,35,48,
+ * 61,66).  Each entry point below replaces one of them (cited per function)
+ * with plain pointers and sizes, so a Rust/C/C++/Python host can bind it.
+ *
+ * Threading: a context owns its device buffers and one HIP stream.  A context
+ * is thread-compatible (one thread at a time), not thread-safe.  The library
+ * keeps no global mutable state.
+ *
+ * Errors: every function returns 0 (JPG_OK) or a negative jpg_status.  The
+ * library never aborts; jpg_strerror() gives the reference's panic text where
+ * one exists.
+ */
+#ifndef JPEG_HIP_H
+#define JPEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum jpg_status {
+    JPG_OK = 0,
+    JPG_ERR_INVALID_RATIO = -1, /* "Invalid chrominance downsampling ratio!"     src/jpeg/sampling.rs:19 */
+    JPG_ERR_DC_RANGE = -2,      /* "DC coefficient bit length greater than 11!"  src/jpeg/entropy_coding.rs:154 */
+    JPG_ERR_AC_RANGE = -3,      /* "AC coefficient bit length greater than 10!"  src/jpeg/entropy_coding.rs:190 */
+    JPG_ERR_HUFF_DC = -4,       /* "DC Huffman Code Not Found!"                  src/jpeg/entropy_coding.rs:212 */
+    JPG_ERR_HUFF_AC = -5,       /* "AC Huffman Code Not Found!"                  src/jpeg/entropy_coding.rs:221 */
+    JPG_ERR_BAD_ARG = -6,
+    JPG_ERR_HIP = -7,           /* a HIP runtime call failed; see jpg_last_hip_error */
+    JPG_ERR_STATE = -8,         /* stage called out of order */
+    JPG_ERR_UNSUPPORTED_DIMS = -9, /* width mod 16 == 1 with h=2 or height mod 16 == 1 with v=2: the
+                                      reference's chroma plane is skewed there (src/jpeg/sampling.rs:56-101
+                                      pushes (Wp/h)*(Hp/v) samples into a plane declared Wc x Hc) */
+    JPG_ERR_NOMEM = -10,
+    JPG_ERR_CAPACITY = -11      /* caller buffer too small */
+} jpg_status;
+
+/* src/jpeg/dct_quant.rs:8-12.  JPG_DCT_REAL is the separable f32 transform
+ * (same cosine table and the same final scale/divide/truncate expression as
+ * the reference; quantised coefficients may differ by +-1 at truncation
+ * boundaries).  JPG_DCT_REAL_STRICT evaluates the reference's 64-term sum in
+ * its own order without FMA and is bit-exact. */
+typedef enum jpg_dct {
+    JPG_DCT_REAL = 0,
+    JPG_DCT_BIN = 1,
+    JPG_DCT_REAL_STRICT = 2
+} jpg_dct;
+
+typedef struct jpg_ctx jpg_ctx;
+
+const char *jpg_strerror(int status);
+/* hipError_t of the last failing HIP call made through this context (0 if none) */
+int jpg_last_hip_error(const jpg_ctx *ctx);
+
+/* JpegImage::new (src/jpeg/jpeg_image.rs:24-102): ratio_a:b:c is the
+ * --subsampling-ratio triple (4:4:4, 4:2:2, 4:2:0; anything else ->
+ * JPG_ERR_INVALID_RATIO).  Buffers are sized at the first load. */
+int jpg_create(jpg_ctx **out, int device, int dct_algo, int ratio_a, int ratio_b, int ratio_c);
+void jpg_destroy(jpg_ctx *ctx);
+/* the context's HIP stream (hipStream_t), for callers that time or order work on it */
+void *jpg_stream(jpg_ctx *ctx);
+/* block until everything queued on the context's stream has finished */
+int jpg_sync(jpg_ctx *ctx);
+
+/* ---- staged path: one call per reference method ------------------------ */
+
+/* JpegImage::from_bmp minus the file parsing (src/jpeg/jpeg_image.rs:104-137,
+ * src/bmp/bmp_image.rs:57-90): `pixels` are BMP rows, 3 bytes B,G,R per
+ * pixel, `row_stride` bytes apart, last image row first when bottom_up != 0.
+ * Host memory; copied to the device before return.  Produces the three u8
+ * planes (padded to the MCU size with zeros). */
+int jpg_load_bgr(jpg_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t height,
+                 uint32_t row_stride, int bottom_up);
+/* same with `pixels` already in device memory (not copied; must stay valid
+ * until the context has been synchronised) */
+int jpg_load_bgr_device(jpg_ctx *ctx, const uint8_t *dev_pixels, int32_t width, int32_t height,
+                        uint32_t row_stride, int bottom_up);
+/* JpegImage::chrominance_downsampling (src/jpeg/sampling.rs:46-102); no-op for 4:4:4 */
+int jpg_downsample(jpg_ctx *ctx);
+/* JpegImage::dct_and_quantization (src/jpeg/dct_quant.rs:15-61) */
+int jpg_dct_quant(jpg_ctx *ctx);
+/* JpegImage::generate_entropy_encoded_data (src/jpeg/entropy_coding.rs:16-125):
+ * produces the MSB-first bit string (= entropy_coded_bits.as_raw_slice(), last
+ * byte zero-padded, no 0xFF stuffing) in device memory; *nbits = its length */
+int jpg_entropy(jpg_ctx *ctx, uint64_t *nbits);
+/* the stuffing loop of write_image_data (src/jpeg/file.rs:92-103), on the
+ * device: 0x00 after every 0xFF byte; *len = stuffed byte count */
+int jpg_stuff(jpg_ctx *ctx, size_t *len);
+
+/* ---- fused path --------------------------------------------------------- */
+
+/* Colour conversion + subsampling + DCT + quantisation as ONE kernel from
+ * device-resident BMP rows straight to quantised coefficients (the u8 planes
+ * are never written to memory).  Asynchronous: returns after queueing. */
+int jpg_front_device(jpg_ctx *ctx, const uint8_t *dev_pixels, int32_t width, int32_t height,
+                     uint32_t row_stride, int bottom_up);
+/* jpg_front_device + entropy coding + stuffing, all queued on the context's
+ * stream without any host synchronisation.  jpg_finish() waits and reports. */
+int jpg_encode_device_async(jpg_ctx *ctx, const uint8_t *dev_pixels, int32_t width, int32_t height,
+                            uint32_t row_stride, int bottom_up);
+/* wait for the queued encode; nbits/stuffed_len may be NULL.  Returns the
+ * reference's range errors (JPG_ERR_DC_RANGE/JPG_ERR_AC_RANGE) if a kernel
+ * met a coefficient the Huffman tables cannot code. */
+int jpg_finish(jpg_ctx *ctx, uint64_t *nbits, size_t *stuffed_len);
+/* everything above from host pixels to a host copy of the stuffed scan bytes
+ * (library-allocated pinned memory; release with jpg_free) */
+int jpg_encode_scan(jpg_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t height,
+                    uint32_t row_stride, int bottom_up, uint8_t **stuffed, size_t *len);
+void jpg_free(void *p);
+
+/* ---- MCU-row stripes of one large image (no counterpart in the reference,
+ * which codes the whole image serially; the arithmetic is that of
+ * src/jpeg/entropy_coding.rs:38-40,149-150 carried across the cut) -------- */
+
+/* Entropy-code the coefficients currently in the context as a stripe whose
+ * three DC predictors start at pred[0..2] (Y, Cb, Cr) instead of 0.  The bit
+ * string starts at bit 0 of the context's buffer. */
+int jpg_entropy_stripe(jpg_ctx *ctx, const int16_t pred[3], uint64_t *nbits);
+/* DC coefficient of the last Y, Cb, Cr block of the stripe in scan order */
+int jpg_last_dc(jpg_ctx *ctx, int16_t dc[3]);
+/* Place this stripe's bit string at global bit offset `bit_offset` of the
+ * whole scan: shift right by bit_offset % 8, OR `head_bits` (the bits of the
+ * previous stripe that share this stripe's first byte, already in place in
+ * the top bits) into the first byte, then apply 0xFF stuffing.  When
+ * !is_last the trailing partial byte is dropped (the next stripe owns it).
+ * *len = stuffed byte count of the piece; *tail = this stripe's bits of the
+ * dropped partial byte (top-aligned), 0 when byte-aligned or is_last. */
+int jpg_stitch(jpg_ctx *ctx, uint64_t bit_offset, uint8_t head_bits, int is_last, size_t *len,
+               uint8_t *tail);
+
+/* ---- results ------------------------------------------------------------ */
+
+/* device pointers of the current results (valid until the next call that
+ * re-encodes or destroys the context) */
+const uint8_t *jpg_bits_device(jpg_ctx *ctx);
+const uint8_t *jpg_scan_device(jpg_ctx *ctx);
+/* copies to host memory; cap = capacity of `out` in bytes */
+int jpg_get_bits(jpg_ctx *ctx, uint8_t *out, size_t cap);
+int jpg_get_scan(jpg_ctx *ctx, uint8_t *out, size_t cap);
+/* public fields y_channel..cr_dct_coeffs of JpegImage (src/jpeg/jpeg_image.rs:
+ * 14-19) in the reference's row-major plane layout; comp 0 Y, 1 Cb, 2 Cr.
+ * Planes exist on the staged path only; coefficients on both. */
+int jpg_plane_dims(jpg_ctx *ctx, int comp, int32_t *w, int32_t *h);
+int jpg_coeff_dims(jpg_ctx *ctx, int comp, int32_t *w, int32_t *h);
+int jpg_get_plane(jpg_ctx *ctx, int comp, uint8_t *out, size_t cap);
+int jpg_get_coeffs(jpg_ctx *ctx, int comp, int16_t *out, size_t cap);
+
+/* ---- introspection for benchmarks --------------------------------------- */
+
+/* algorithmic bytes one fused front launch moves for the current image:
+ * row_stride*H read + 2 bytes per quantised coefficient written */
+uint64_t jpg_front_bytes(const jpg_ctx *ctx);
+/* number of 8x8 blocks (all components) of the current image */
+uint64_t jpg_num_blocks(const jpg_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

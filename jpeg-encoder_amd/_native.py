@@ -1,0 +1,90 @@
+"""ctypes binding of libjpeg_hip.so (C ABI in include/jpeg_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, an
+exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjpeg_hip.so")
+
+DCT_REAL, DCT_BIN, DCT_REAL_STRICT = 0, 1, 2
+
+# every symbol include/jpeg_hip.h declares
+SYMBOLS = [
+    "jpg_strerror", "jpg_last_hip_error", "jpg_create", "jpg_destroy", "jpg_stream", "jpg_sync",
+    "jpg_load_bgr", "jpg_load_bgr_device", "jpg_downsample", "jpg_dct_quant", "jpg_entropy", "jpg_stuff",
+    "jpg_front_device", "jpg_encode_device_async", "jpg_finish", "jpg_encode_scan", "jpg_free",
+    "jpg_entropy_stripe", "jpg_last_dc", "jpg_stitch", "jpg_bits_device", "jpg_scan_device",
+    "jpg_get_bits", "jpg_get_scan", "jpg_plane_dims", "jpg_coeff_dims", "jpg_get_plane", "jpg_get_coeffs",
+    "jpg_front_bytes", "jpg_num_blocks",
+]
+
+
+class JpgError(RuntimeError):
+    """A negative jpg_status; the message is the reference's panic text where one exists."""
+
+    def __init__(self, code, message, hip_error=0):
+        super().__init__("%s (status %d%s)" % (message, code, ", hipError %d" % hip_error if hip_error else ""))
+        self.code = code
+        self.hip_error = hip_error
+
+
+_lib = None
+
+
+def lib():
+    """Load libjpeg_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `python jpeg-encoder_amd/build.py`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, u64p, szp = C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)
+    L.jpg_strerror.argtypes = [C.c_int]
+    L.jpg_strerror.restype = C.c_char_p
+    L.jpg_last_hip_error.argtypes = [vp]
+    L.jpg_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.jpg_destroy.argtypes = [vp]
+    L.jpg_destroy.restype = None
+    L.jpg_stream.argtypes = [vp]
+    L.jpg_stream.restype = vp
+    L.jpg_sync.argtypes = [vp]
+    for name in ("jpg_load_bgr", "jpg_load_bgr_device", "jpg_front_device", "jpg_encode_device_async"):
+        getattr(L, name).argtypes = [vp, vp, i32, i32, u32, C.c_int]
+    L.jpg_downsample.argtypes = [vp]
+    L.jpg_dct_quant.argtypes = [vp]
+    L.jpg_entropy.argtypes = [vp, u64p]
+    L.jpg_stuff.argtypes = [vp, szp]
+    L.jpg_finish.argtypes = [vp, u64p, szp]
+    L.jpg_encode_scan.argtypes = [vp, vp, i32, i32, u32, C.c_int, C.POINTER(vp), szp]
+    L.jpg_free.argtypes = [vp]
+    L.jpg_free.restype = None
+    L.jpg_entropy_stripe.argtypes = [vp, C.POINTER(C.c_int16), u64p]
+    L.jpg_last_dc.argtypes = [vp, C.POINTER(C.c_int16)]
+    L.jpg_stitch.argtypes = [vp, C.c_uint64, C.c_uint8, C.c_int, szp, C.POINTER(C.c_uint8)]
+    L.jpg_bits_device.argtypes = [vp]
+    L.jpg_bits_device.restype = vp
+    L.jpg_scan_device.argtypes = [vp]
+    L.jpg_scan_device.restype = vp
+    L.jpg_get_bits.argtypes = [vp, vp, C.c_size_t]
+    L.jpg_get_scan.argtypes = [vp, vp, C.c_size_t]
+    L.jpg_plane_dims.argtypes = [vp, C.c_int, C.POINTER(i32), C.POINTER(i32)]
+    L.jpg_coeff_dims.argtypes = [vp, C.c_int, C.POINTER(i32), C.POINTER(i32)]
+    L.jpg_get_plane.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.jpg_get_coeffs.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.jpg_front_bytes.argtypes = [vp]
+    L.jpg_front_bytes.restype = C.c_uint64
+    L.jpg_num_blocks.argtypes = [vp]
+    L.jpg_num_blocks.restype = C.c_uint64
+    _lib = L
+    return L
+
+
+def check(ctx, status):
+    if status != 0:
+        L = lib()
+        hip = L.jpg_last_hip_error(ctx) if ctx else 0
+        raise JpgError(status, L.jpg_strerror(status).decode(), hip)

@@ -1,0 +1,511 @@
+// C ABI of libjpeg_hip.so (declared in include/jpeg_hip.h): context and buffer
+// management around the kernels of front.hip, staged.hip and entropy.hip.
+#include "../../include/jpeg_hip.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "internal.hpp"
+
+using namespace jpg;
+
+enum Stage { ST_NONE = 0, ST_PLANES = 1, ST_DOWN = 2, ST_COEF = 3, ST_BITS = 4, ST_SCAN = 5 };
+
+struct jpg_ctx {
+    int device = 0;
+    int algo = 0;
+    int h = 1, v = 1;
+    hipStream_t stream = nullptr;
+    int last_hip = 0;
+    int stage = ST_NONE;
+    bool have_planes = false;   // staged u8 planes are valid
+    bool down_done = false;
+    bool pending = false;       // an async encode awaits jpg_finish
+    Geom g{};
+
+    uint8_t *d_src_own = nullptr; size_t src_cap = 0;
+    const uint8_t *d_src = nullptr;
+    uint8_t *d_plane[3] = {nullptr, nullptr, nullptr}; size_t plane_cap = 0;   // Wp x Hp each
+    uint8_t *d_down[2] = {nullptr, nullptr}; size_t down_cap = 0;              // Wc x Hc each
+    int16_t *d_coef = nullptr; size_t coef_cap = 0;                            // in blocks
+    int16_t *d_tmp16 = nullptr; size_t tmp16_cap = 0;
+    int16_t *d_pred = nullptr;   // [0..2] predictors in, [4..6] last DCs out
+    EntropyBufs eb{};
+    size_t ent_cap = 0;          // in blocks
+    uint64_t *h_totals = nullptr;  // pinned: [0] bits [1] stuffed bytes
+    int *h_err = nullptr;          // pinned
+    uint8_t *h_tail = nullptr;     // pinned
+    uint64_t nbits = 0;
+    size_t scan_len = 0;
+};
+
+#define HIP_TRY(ctx, expr)                   \
+    do {                                     \
+        hipError_t _e = (expr);              \
+        if (_e != hipSuccess) {              \
+            (ctx)->last_hip = (int)_e;       \
+            (void)hipGetLastError();         \
+            return JPG_ERR_HIP;              \
+        }                                    \
+    } while (0)
+
+extern "C" const char *jpg_strerror(int st) {
+    switch (st) {
+        case JPG_OK: return "ok";
+        case JPG_ERR_INVALID_RATIO: return "Invalid chrominance downsampling ratio!";
+        case JPG_ERR_DC_RANGE: return "DC coefficient bit length greater than 11!";
+        case JPG_ERR_AC_RANGE: return "AC coefficient bit length greater than 10!";
+        case JPG_ERR_HUFF_DC: return "DC Huffman Code Not Found!";
+        case JPG_ERR_HUFF_AC: return "AC Huffman Code Not Found!";
+        case JPG_ERR_BAD_ARG: return "bad argument";
+        case JPG_ERR_HIP: return "HIP runtime error";
+        case JPG_ERR_STATE: return "stage called out of order";
+        case JPG_ERR_UNSUPPORTED_DIMS:
+            return "unsupported dimensions: the reference skews the chroma plane when width %% 16 == 1 (h=2) or "
+                   "height %% 16 == 1 (v=2)";
+        case JPG_ERR_NOMEM: return "out of memory";
+        case JPG_ERR_CAPACITY: return "output buffer too small";
+    }
+    return "unknown status";
+}
+
+extern "C" int jpg_last_hip_error(const jpg_ctx *ctx) { return ctx ? ctx->last_hip : 0; }
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+static int use_device(jpg_ctx *c) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    return JPG_OK;
+}
+
+template <class T>
+static int grow(jpg_ctx *c, T *&p, size_t &cap, size_t need_elems) {
+    if (need_elems <= cap && p) return JPG_OK;
+    if (p) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(p));
+        p = nullptr;
+        cap = 0;
+    }
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, need_elems * sizeof(T));
+    if (e != hipSuccess) {
+        c->last_hip = (int)e;
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? JPG_ERR_NOMEM : JPG_ERR_HIP;
+    }
+    p = static_cast<T *>(q);
+    cap = need_elems;
+    return JPG_OK;
+}
+
+extern "C" int jpg_create(jpg_ctx **out, int device, int dct_algo, int ra, int rb, int rc) {
+    if (!out) return JPG_ERR_BAD_ARG;
+    *out = nullptr;
+    int h, v;
+    // src/jpeg/sampling.rs:6-22
+    if (ra == 4 && rb == 4 && rc == 4) { h = 1; v = 1; }
+    else if (ra == 4 && rb == 2 && rc == 0) { h = 2; v = 2; }
+    else if (ra == 4 && rb == 2 && rc == 2) { h = 2; v = 1; }
+    else return JPG_ERR_INVALID_RATIO;
+    if (dct_algo != JPG_DCT_REAL && dct_algo != JPG_DCT_BIN && dct_algo != JPG_DCT_REAL_STRICT) return JPG_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        (void)hipGetLastError();
+        return JPG_ERR_HIP;
+    }
+    jpg_ctx *c = new (std::nothrow) jpg_ctx();
+    if (!c) return JPG_ERR_NOMEM;
+    c->device = device; c->algo = dct_algo; c->h = h; c->v = v;
+    bool ok = hipSetDevice(device) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_totals, 4 * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_err, sizeof(int), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_tail, 16, hipHostMallocDefault) == hipSuccess &&
+              hipMalloc((void **)&c->d_pred, 8 * sizeof(int16_t)) == hipSuccess &&
+              hipMalloc((void **)&c->eb.totals, 4 * sizeof(uint64_t)) == hipSuccess &&
+              hipMalloc((void **)&c->eb.error, sizeof(int)) == hipSuccess &&
+              hipMalloc((void **)&c->eb.tail, 16) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        jpg_destroy(c);
+        return JPG_ERR_HIP;
+    }
+    *out = c;
+    return JPG_OK;
+}
+
+extern "C" void jpg_destroy(jpg_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *dev[] = {c->d_src_own, c->d_plane[0], c->d_plane[1], c->d_plane[2], c->d_down[0], c->d_down[1], c->d_coef,
+                   c->d_tmp16, c->d_pred, c->eb.chunk_len, c->eb.chunk_off, c->eb.group_len, c->eb.group_base,
+                   c->eb.totals, c->eb.error, c->eb.bits, c->eb.seg_cnt, c->eb.seg_off, c->eb.scan, c->eb.tail};
+    for (void *p : dev)
+        if (p) (void)hipFree(p);
+    if (c->h_totals) (void)hipHostFree(c->h_totals);
+    if (c->h_err) (void)hipHostFree(c->h_err);
+    if (c->h_tail) (void)hipHostFree(c->h_tail);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void *jpg_stream(jpg_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int jpg_sync(jpg_ctx *c) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (int e = use_device(c)) return e;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return JPG_OK;
+}
+
+// JpegImage::new's dimension arithmetic (src/jpeg/jpeg_image.rs:36-56)
+static int set_geometry(jpg_ctx *c, int32_t W, int32_t H, uint32_t stride, int bottom_up) {
+    if (W <= 0 || H <= 0 || (uint64_t)stride < (uint64_t)3 * (uint64_t)W) return JPG_ERR_BAD_ARG;
+    Geom g{};
+    g.W = W; g.H = H; g.h = c->h; g.v = c->v;
+    g.Wp = round_up(W, 8 * g.h); g.Hp = round_up(H, 8 * g.v);
+    g.Wc = round_up(W / g.h, 8); g.Hc = round_up(H / g.v, 8);
+    if (g.Wc != g.Wp / g.h || g.Hc != g.Hp / g.v) return JPG_ERR_UNSUPPORTED_DIMS;
+    g.mcux = g.Wp / (8 * g.h); g.mcuy = g.Hp / (8 * g.v);
+    g.nb = g.h * g.v + 2;
+    g.stride = stride; g.bottom_up = bottom_up ? 1 : 0;
+    g.nblocks = (long long)g.mcux * g.mcuy * g.nb;
+    c->g = g;
+    c->stage = ST_NONE; c->have_planes = false; c->down_done = false;
+    return JPG_OK;
+}
+
+static int ensure_coef(jpg_ctx *c) {
+    const size_t nblk = (size_t)c->g.nblocks;
+    return grow(c, c->d_coef, c->coef_cap, nblk * 64);
+}
+
+static int ensure_entropy(jpg_ctx *c) {
+    const size_t nblk = (size_t)c->g.nblocks;
+    if (nblk <= c->ent_cap) return JPG_OK;
+    const size_t nchunks = (nblk + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
+    const size_t ngroups = (nchunks + GROUP_CHUNKS - 1) / GROUP_CHUNKS;
+    // worst case: every block at its maximum coded size
+    size_t bits_bytes = (nblk * MAX_BLOCK_BITS + 7) / 8 + 64;
+    bits_bytes = (bits_bytes + 15) / 16 * 16;
+    const size_t scan_bytes = 2 * bits_bytes + 16;
+    const size_t nseg = bits_bytes / STUFF_SEG + 2;
+    int e;
+    auto re = [&](auto *&p, size_t n) -> int {
+        size_t cc = 0;
+        if (p) {
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipFree(p);
+            p = nullptr;
+        }
+        return grow(c, p, cc, n);
+    };
+    if ((e = re(c->eb.chunk_len, nchunks))) return e;
+    if ((e = re(c->eb.chunk_off, nchunks))) return e;
+    if ((e = re(c->eb.group_len, ngroups))) return e;
+    if ((e = re(c->eb.group_base, ngroups))) return e;
+    if ((e = re(c->eb.bits, bits_bytes / 4))) return e;
+    if ((e = re(c->eb.seg_cnt, nseg))) return e;
+    if ((e = re(c->eb.seg_off, nseg))) return e;
+    if ((e = re(c->eb.scan, scan_bytes))) return e;
+    c->eb.bits_cap = bits_bytes;
+    c->eb.scan_cap = scan_bytes;
+    c->eb.nseg_cap = nseg;
+    c->ent_cap = nblk;
+    return JPG_OK;
+}
+
+// Make `pixels` usable by the kernels: device-resident, 4-byte aligned base
+// and stride.  Host memory is always copied; device memory only if misaligned.
+static int stage_input(jpg_ctx *c, const uint8_t *pixels, bool on_host) {
+    Geom &g = c->g;
+    const bool aligned = ((g.stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(pixels) & 3) == 0);
+    if (!on_host && aligned) {
+        c->d_src = pixels;
+        return JPG_OK;
+    }
+    const uint32_t pitch = (g.stride & 3) == 0 ? g.stride : (uint32_t)round_up(3 * g.W, 4);
+    if (int e = grow(c, c->d_src_own, c->src_cap, (size_t)pitch * g.H + 16)) return e;
+    HIP_TRY(c, hipMemcpy2DAsync(c->d_src_own, pitch, pixels, g.stride, (size_t)3 * g.W, (size_t)g.H,
+                                on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+    g.stride = pitch;
+    c->d_src = c->d_src_own;
+    return JPG_OK;
+}
+
+static int load_common(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride, int bottom_up,
+                       bool on_host) {
+    if (!c || !pixels) return JPG_ERR_BAD_ARG;
+    if (int e = use_device(c)) return e;
+    if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
+    if (int e = stage_input(c, pixels, on_host)) return e;
+    const size_t n = (size_t)c->g.Wp * c->g.Hp;
+    if (n > c->plane_cap || !c->d_plane[0]) {
+        for (int k = 0; k < 3; k++) {
+            size_t cap = 0;
+            if (c->d_plane[k]) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->d_plane[k]); c->d_plane[k] = nullptr; }
+            if (int e = grow(c, c->d_plane[k], cap, n)) return e;
+        }
+        c->plane_cap = n;
+    }
+    HIP_TRY(c, launch_color(c->g, c->d_src, c->d_plane[0], c->d_plane[1], c->d_plane[2], c->stream));
+    if (on_host) HIP_TRY(c, hipStreamSynchronize(c->stream));   // caller may reuse `pixels`
+    c->stage = ST_PLANES; c->have_planes = true; c->down_done = false;
+    return JPG_OK;
+}
+
+extern "C" int jpg_load_bgr(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride, int bottom_up) {
+    return load_common(c, pixels, W, H, stride, bottom_up, true);
+}
+extern "C" int jpg_load_bgr_device(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride,
+                                   int bottom_up) {
+    return load_common(c, pixels, W, H, stride, bottom_up, false);
+}
+
+extern "C" int jpg_downsample(jpg_ctx *c) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (c->stage != ST_PLANES) return JPG_ERR_STATE;
+    if (int e = use_device(c)) return e;
+    if (c->h != 1 || c->v != 1) {
+        const size_t n = (size_t)c->g.Wc * c->g.Hc;
+        if (n > c->down_cap || !c->d_down[0]) {
+            for (int k = 0; k < 2; k++) {
+                size_t cap = 0;
+                if (c->d_down[k]) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->d_down[k]); c->d_down[k] = nullptr; }
+                if (int e = grow(c, c->d_down[k], cap, n)) return e;
+            }
+            c->down_cap = n;
+        }
+        HIP_TRY(c, launch_downsample(c->g, c->d_plane[1], c->d_plane[2], c->d_down[0], c->d_down[1], c->stream));
+    }
+    c->stage = ST_DOWN; c->down_done = true;
+    return JPG_OK;
+}
+
+extern "C" int jpg_dct_quant(jpg_ctx *c) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (c->stage != ST_DOWN) return JPG_ERR_STATE;
+    if (int e = use_device(c)) return e;
+    if (int e = ensure_coef(c)) return e;
+    const bool sub = c->h != 1 || c->v != 1;
+    HIP_TRY(c, launch_dct_planes(c->g, c->algo, c->d_plane[0], sub ? c->d_down[0] : c->d_plane[1],
+                                 sub ? c->d_down[1] : c->d_plane[2], c->d_coef, c->stream));
+    c->stage = ST_COEF;
+    return JPG_OK;
+}
+
+static int queue_entropy(jpg_ctx *c, const int16_t pred[3]) {
+    if (int e = ensure_entropy(c)) return e;
+    if (pred) {
+        // small, synchronous with respect to the host buffer
+        int16_t *hp = reinterpret_cast<int16_t *>(c->h_tail) + 4;
+        hp[0] = pred[0]; hp[1] = pred[1]; hp[2] = pred[2];
+        HIP_TRY(c, hipMemcpyAsync(c->d_pred, hp, 3 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIP_TRY(c, hipMemsetAsync(c->d_pred, 0, 3 * sizeof(int16_t), c->stream));
+    }
+    HIP_TRY(c, launch_entropy(c->g, c->d_coef, c->d_pred, c->eb, c->stream));
+    return JPG_OK;
+}
+
+static int fetch_totals(jpg_ctx *c) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_totals, c->eb.totals, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_err, c->eb.error, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_tail, c->eb.tail, 1, hipMemcpyDeviceToHost, c->stream));
+    return JPG_OK;
+}
+
+static int entropy_common(jpg_ctx *c, const int16_t *pred, uint64_t *nbits) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_COEF) return JPG_ERR_STATE;
+    if (int e = use_device(c)) return e;
+    if (int e = queue_entropy(c, pred)) return e;
+    if (int e = fetch_totals(c)) return e;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (*c->h_err) return *c->h_err;
+    c->nbits = c->h_totals[0];
+    if (nbits) *nbits = c->nbits;
+    c->stage = ST_BITS;
+    return JPG_OK;
+}
+
+extern "C" int jpg_entropy(jpg_ctx *c, uint64_t *nbits) { return entropy_common(c, nullptr, nbits); }
+extern "C" int jpg_entropy_stripe(jpg_ctx *c, const int16_t pred[3], uint64_t *nbits) {
+    if (!pred) return JPG_ERR_BAD_ARG;
+    return entropy_common(c, pred, nbits);
+}
+
+extern "C" int jpg_last_dc(jpg_ctx *c, int16_t dc[3]) {
+    if (!c || !dc) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_COEF) return JPG_ERR_STATE;
+    if (int e = use_device(c)) return e;
+    HIP_TRY(c, launch_last_dc(c->g, c->d_coef, c->d_pred + 4, c->stream));
+    int16_t *hp = reinterpret_cast<int16_t *>(c->h_tail) + 4;
+    HIP_TRY(c, hipMemcpyAsync(hp, c->d_pred + 4, 3 * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dc[0] = hp[0]; dc[1] = hp[1]; dc[2] = hp[2];
+    return JPG_OK;
+}
+
+extern "C" int jpg_stitch(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, int is_last, size_t *len, uint8_t *tail) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_BITS) return JPG_ERR_STATE;
+    if (int e = use_device(c)) return e;
+    HIP_TRY(c, launch_stuff(c->eb, bit_offset, head_bits, is_last, c->stream));
+    if (int e = fetch_totals(c)) return e;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->scan_len = (size_t)c->h_totals[1];
+    if (len) *len = c->scan_len;
+    if (tail) *tail = c->h_tail[0];
+    c->stage = ST_SCAN;
+    return JPG_OK;
+}
+
+extern "C" int jpg_stuff(jpg_ctx *c, size_t *len) { return jpg_stitch(c, 0, 0, 1, len, nullptr); }
+
+extern "C" int jpg_front_device(jpg_ctx *c, const uint8_t *dev_pixels, int32_t W, int32_t H, uint32_t stride,
+                                int bottom_up) {
+    if (!c || !dev_pixels) return JPG_ERR_BAD_ARG;
+    if (int e = use_device(c)) return e;
+    if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
+    if (int e = stage_input(c, dev_pixels, false)) return e;
+    if (int e = ensure_coef(c)) return e;
+    HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream));
+    c->stage = ST_COEF;
+    return JPG_OK;
+}
+
+extern "C" int jpg_encode_device_async(jpg_ctx *c, const uint8_t *dev_pixels, int32_t W, int32_t H, uint32_t stride,
+                                       int bottom_up) {
+    if (int e = jpg_front_device(c, dev_pixels, W, H, stride, bottom_up)) return e;
+    if (int e = queue_entropy(c, nullptr)) return e;
+    HIP_TRY(c, launch_stuff(c->eb, 0, 0, 1, c->stream));
+    if (int e = fetch_totals(c)) return e;
+    c->pending = true;
+    return JPG_OK;
+}
+
+extern "C" int jpg_finish(jpg_ctx *c, uint64_t *nbits, size_t *stuffed_len) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (!c->pending) return JPG_ERR_STATE;
+    if (int e = use_device(c)) return e;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->pending = false;
+    if (*c->h_err) return *c->h_err;
+    c->nbits = c->h_totals[0];
+    c->scan_len = (size_t)c->h_totals[1];
+    if (nbits) *nbits = c->nbits;
+    if (stuffed_len) *stuffed_len = c->scan_len;
+    c->stage = ST_SCAN;
+    return JPG_OK;
+}
+
+extern "C" int jpg_encode_scan(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride, int bottom_up,
+                               uint8_t **stuffed, size_t *len) {
+    if (!c || !pixels || !stuffed || !len) return JPG_ERR_BAD_ARG;
+    *stuffed = nullptr; *len = 0;
+    if (int e = use_device(c)) return e;
+    if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
+    if (int e = stage_input(c, pixels, true)) return e;
+    if (int e = ensure_coef(c)) return e;
+    HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream));
+    c->stage = ST_COEF;
+    if (int e = queue_entropy(c, nullptr)) return e;
+    HIP_TRY(c, launch_stuff(c->eb, 0, 0, 1, c->stream));
+    if (int e = fetch_totals(c)) return e;
+    c->pending = true;
+    if (int e = jpg_finish(c, nullptr, nullptr)) return e;
+    void *host = nullptr;
+    hipError_t he = hipHostMalloc(&host, c->scan_len ? c->scan_len : 1, hipHostMallocDefault);
+    if (he != hipSuccess) { c->last_hip = (int)he; (void)hipGetLastError(); return JPG_ERR_NOMEM; }
+    he = hipMemcpyAsync(host, c->eb.scan, c->scan_len, hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (he != hipSuccess) { (void)hipHostFree(host); c->last_hip = (int)he; (void)hipGetLastError(); return JPG_ERR_HIP; }
+    *stuffed = static_cast<uint8_t *>(host);
+    *len = c->scan_len;
+    return JPG_OK;
+}
+
+extern "C" void jpg_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+extern "C" const uint8_t *jpg_bits_device(jpg_ctx *c) {
+    return c && c->stage >= ST_BITS ? reinterpret_cast<const uint8_t *>(c->eb.bits) : nullptr;
+}
+extern "C" const uint8_t *jpg_scan_device(jpg_ctx *c) { return c && c->stage >= ST_SCAN ? c->eb.scan : nullptr; }
+
+extern "C" int jpg_get_bits(jpg_ctx *c, uint8_t *out, size_t cap) {
+    if (!c || !out) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_BITS) return JPG_ERR_STATE;
+    const size_t n = (size_t)((c->nbits + 7) >> 3);
+    if (cap < n) return JPG_ERR_CAPACITY;
+    if (int e = use_device(c)) return e;
+    HIP_TRY(c, hipMemcpyAsync(out, c->eb.bits, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return JPG_OK;
+}
+
+extern "C" int jpg_get_scan(jpg_ctx *c, uint8_t *out, size_t cap) {
+    if (!c || !out) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_SCAN) return JPG_ERR_STATE;
+    if (cap < c->scan_len) return JPG_ERR_CAPACITY;
+    if (int e = use_device(c)) return e;
+    HIP_TRY(c, hipMemcpyAsync(out, c->eb.scan, c->scan_len, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return JPG_OK;
+}
+
+extern "C" int jpg_plane_dims(jpg_ctx *c, int comp, int32_t *w, int32_t *h) {
+    if (!c || comp < 0 || comp > 2) return JPG_ERR_BAD_ARG;
+    if (c->stage == ST_NONE) return JPG_ERR_STATE;
+    const bool down = comp > 0 && c->down_done && (c->h != 1 || c->v != 1);
+    if (w) *w = down ? c->g.Wc : c->g.Wp;
+    if (h) *h = down ? c->g.Hc : c->g.Hp;
+    return JPG_OK;
+}
+
+extern "C" int jpg_coeff_dims(jpg_ctx *c, int comp, int32_t *w, int32_t *h) {
+    if (!c || comp < 0 || comp > 2) return JPG_ERR_BAD_ARG;
+    if (c->stage == ST_NONE) return JPG_ERR_STATE;
+    if (w) *w = comp ? c->g.Wc : c->g.Wp;
+    if (h) *h = comp ? c->g.Hc : c->g.Hp;
+    return JPG_OK;
+}
+
+extern "C" int jpg_get_plane(jpg_ctx *c, int comp, uint8_t *out, size_t cap) {
+    if (!c || !out || comp < 0 || comp > 2) return JPG_ERR_BAD_ARG;
+    if (!c->have_planes) return JPG_ERR_STATE;
+    int32_t w, h;
+    if (int e = jpg_plane_dims(c, comp, &w, &h)) return e;
+    const size_t n = (size_t)w * h;
+    if (cap < n) return JPG_ERR_CAPACITY;
+    if (int e = use_device(c)) return e;
+    const bool down = comp > 0 && c->down_done && (c->h != 1 || c->v != 1);
+    const uint8_t *src = down ? c->d_down[comp - 1] : c->d_plane[comp];
+    HIP_TRY(c, hipMemcpyAsync(out, src, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return JPG_OK;
+}
+
+extern "C" int jpg_get_coeffs(jpg_ctx *c, int comp, int16_t *out, size_t cap) {
+    if (!c || !out || comp < 0 || comp > 2) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_COEF) return JPG_ERR_STATE;
+    const size_t n = comp ? (size_t)c->g.Wc * c->g.Hc : (size_t)c->g.Wp * c->g.Hp;
+    if (cap < n * sizeof(int16_t)) return JPG_ERR_CAPACITY;
+    if (int e = use_device(c)) return e;
+    if (int e = grow(c, c->d_tmp16, c->tmp16_cap, n)) return e;
+    HIP_TRY(c, launch_unscan(c->g, c->d_coef, comp, c->d_tmp16, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_tmp16, n * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return JPG_OK;
+}
+
+extern "C" uint64_t jpg_front_bytes(const jpg_ctx *c) {
+    if (!c || c->g.W == 0) return 0;
+    return (uint64_t)c->g.stride * c->g.H + 2ull * 64ull * (uint64_t)c->g.nblocks;
+}
+extern "C" uint64_t jpg_num_blocks(const jpg_ctx *c) { return c ? (uint64_t)c->g.nblocks : 0; }

@@ -1,0 +1,174 @@
+// Fused front end: BMP rows (B,G,R bytes) -> YCbCr -> chroma box average ->
+// level shift -> 8x8 DCT -> quantisation -> zigzag, one kernel, no plane ever
+// written to memory.  Replaces the loop of JpegImage::from_bmp
+// (src/jpeg/jpeg_image.rs:121-134), chrominance_downsampling
+// (src/jpeg/sampling.rs:46-102) and dct_and_quantization
+// (src/jpeg/dct_quant.rs:15-61) of the reference.
+//
+// One workgroup owns a tile of 512 pixels x one MCU row (8*v image rows):
+//   phase A  every thread converts groups of 4 pixels x v rows read straight
+//            from global memory (12 contiguous bytes per row and lane, so a
+//            wave reads 768 contiguous bytes) and leaves Y and the averaged
+//            Cb/Cr as bytes in LDS;
+//   phase B  one thread per 8x8 block (wave-uniform component class, so the
+//            quantisation table is a compile-time constant) transforms it in
+//            registers and parks the 128-byte zigzag block in LDS;
+//   phase C  the tile's blocks, contiguous in the scan layout, go to global
+//            memory as coalesced 16-byte stores.
+// HBM traffic is the algorithmic minimum: every input byte is read once, every
+// coefficient written once.
+#include "internal.hpp"
+#include "transform.hpp"
+
+namespace jpg {
+
+constexpr int TILE_W = 512;     // pixels per tile row
+constexpr int OUT_STRIDE = 144; // bytes between parked blocks in LDS (128 + 16: conflict-free b128 access)
+
+template <int HS, int VS>
+struct TileCfg {
+    static constexpr int MCUS = TILE_W / (8 * HS);           // MCUs per tile
+    static constexpr int NBLK = HS * VS + 2;                  // blocks per MCU
+    static constexpr int TILE_H = 8 * VS;                     // image rows per tile
+    static constexpr int YWAVES = VS;                         // 64 luma blocks per block row
+    static constexpr int CWAVES = (2 * MCUS) / 64;            // chroma blocks: MCUS per component
+    static constexpr int THREADS = 64 * (YWAVES + CWAVES);
+    static constexpr int CW = TILE_W / HS;                    // chroma samples per tile row
+    static constexpr int BLOCKS = MCUS * NBLK;
+};
+
+template <int HS, int VS, int ALGO>
+__global__ __launch_bounds__((TileCfg<HS, VS>::THREADS)) void k_front(const uint8_t *__restrict__ src, Geom g,
+                                                                      int16_t *__restrict__ coef) {
+    using C = TileCfg<HS, VS>;
+    __shared__ __attribute__((aligned(16))) uint8_t sY[C::TILE_H][TILE_W];
+    __shared__ __attribute__((aligned(16))) uint8_t sC[2][8][C::CW];
+    __shared__ __attribute__((aligned(16))) uint8_t sOut[C::BLOCKS * OUT_STRIDE];
+
+    const int tiles_x = (g.mcux + C::MCUS - 1) / C::MCUS;
+    const int tile_x = blockIdx.x % tiles_x;
+    const int tile_y = blockIdx.x / tiles_x;
+    const int mcu0 = tile_x * C::MCUS;                        // first MCU column of the tile
+    const int mcus = min(C::MCUS, g.mcux - mcu0);             // MCUs really present
+    const int x0 = mcu0 * 8 * HS;
+    const int y0 = tile_y * C::TILE_H;
+    const int tid = threadIdx.x;
+
+    // ---------------- phase A: colour conversion + chroma average ----------
+    const int items_x = mcus * 2 * HS;                        // groups of 4 pixels across the tile
+    const bool rows_inside = (y0 + C::TILE_H <= g.H);
+    for (int it = tid; it < items_x * 8; it += C::THREADS) {
+        const int ix = it % items_x;
+        const int iy = it / items_x;                          // chroma row inside the tile, 0..7
+        const int x = x0 + 4 * ix;
+        uint32_t cbs[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < VS; r++) {
+            const int ly = iy * VS + r;
+            const int y = y0 + ly;
+            uint32_t yy[4] = {0, 0, 0, 0}, cb[4] = {0, 0, 0, 0}, cr[4] = {0, 0, 0, 0};
+            if (rows_inside && x + 4 <= g.W) {
+                const size_t row = (size_t)(g.bottom_up ? g.H - 1 - y : y) * g.stride;
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(src + row + (size_t)3 * x);
+                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+                // bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+                rgb_to_ycbcr((float)((d0 >> 16) & 0xff), (float)((d0 >> 8) & 0xff), (float)(d0 & 0xff), yy[0], cb[0], cr[0]);
+                rgb_to_ycbcr((float)((d1 >> 8) & 0xff), (float)(d1 & 0xff), (float)(d0 >> 24), yy[1], cb[1], cr[1]);
+                rgb_to_ycbcr((float)(d2 & 0xff), (float)(d1 >> 24), (float)((d1 >> 16) & 0xff), yy[2], cb[2], cr[2]);
+                rgb_to_ycbcr((float)(d2 >> 24), (float)((d2 >> 16) & 0xff), (float)((d2 >> 8) & 0xff), yy[3], cb[3], cr[3]);
+            } else if (y < g.H) {
+                // image edge: samples outside W x H stay 0 in all three planes
+                // (zero-filled planes of src/jpeg/jpeg_image.rs:59-70)
+                const uint8_t *p = src + (size_t)(g.bottom_up ? g.H - 1 - y : y) * g.stride;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (x + k < g.W) {
+                        const uint8_t *q = p + (size_t)3 * (x + k);
+                        rgb_to_ycbcr((float)q[2], (float)q[1], (float)q[0], yy[k], cb[k], cr[k]);
+                    }
+            }
+            *reinterpret_cast<uint32_t *>(&sY[ly][4 * ix]) = yy[0] | (yy[1] << 8) | (yy[2] << 16) | (yy[3] << 24);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { cbs[k] += cb[k]; crs[k] += cr[k]; }
+        }
+        // box average, floor(sum / (h*v)) (src/jpeg/sampling.rs:66-73)
+        if constexpr (HS == 2) {
+            const uint32_t b0 = (cbs[0] + cbs[1]) / (2 * VS), b1 = (cbs[2] + cbs[3]) / (2 * VS);
+            const uint32_t r0 = (crs[0] + crs[1]) / (2 * VS), r1 = (crs[2] + crs[3]) / (2 * VS);
+            *reinterpret_cast<uint16_t *>(&sC[0][iy][2 * ix]) = (uint16_t)(b0 | (b1 << 8));
+            *reinterpret_cast<uint16_t *>(&sC[1][iy][2 * ix]) = (uint16_t)(r0 | (r1 << 8));
+        } else {
+            *reinterpret_cast<uint32_t *>(&sC[0][iy][4 * ix]) = cbs[0] | (cbs[1] << 8) | (cbs[2] << 16) | (cbs[3] << 24);
+            *reinterpret_cast<uint32_t *>(&sC[1][iy][4 * ix]) = crs[0] | (crs[1] << 8) | (crs[2] << 16) | (crs[3] << 24);
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase B: one thread per 8x8 block ---------------------
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave < C::YWAVES) {
+        // luma: block row `wave`, block column `lane` of the tile
+        const int m = lane / HS;                               // MCU inside the tile
+        if (m < mcus) {
+            uint32_t px[16];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint2 d = *reinterpret_cast<const uint2 *>(&sY[wave * 8 + r][lane * 8]);
+                px[2 * r] = d.x;
+                px[2 * r + 1] = d.y;
+            }
+            const int bi = m * C::NBLK + wave * HS + (lane % HS);
+            transform_block<ALGO, false>(px, reinterpret_cast<uint32_t *>(&sOut[bi * OUT_STRIDE]));
+        }
+    } else {
+        const int ci = (wave - C::YWAVES) * 64 + lane;         // 0 .. 2*MCUS-1
+        const int comp = ci / C::MCUS;                         // 0 Cb, 1 Cr
+        const int m = ci % C::MCUS;
+        if (m < mcus) {
+            uint32_t px[16];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint2 d = *reinterpret_cast<const uint2 *>(&sC[comp][r][m * 8]);
+                px[2 * r] = d.x;
+                px[2 * r + 1] = d.y;
+            }
+            const int bi = m * C::NBLK + HS * VS + comp;
+            transform_block<ALGO, true>(px, reinterpret_cast<uint32_t *>(&sOut[bi * OUT_STRIDE]));
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase C: coalesced copy-out ---------------------------
+    const size_t first_block = ((size_t)tile_y * g.mcux + mcu0) * C::NBLK;
+    uint4 *dst = reinterpret_cast<uint4 *>(coef + first_block * 64);
+    const int units = mcus * C::NBLK * 8;                      // 16-byte pieces
+    for (int u = tid; u < units; u += C::THREADS)
+        dst[u] = *reinterpret_cast<const uint4 *>(&sOut[(u >> 3) * OUT_STRIDE + (u & 7) * 16]);
+}
+
+template <int HS, int VS>
+static hipError_t launch_front_hv(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s) {
+    using C = TileCfg<HS, VS>;
+    const int tiles_x = (g.mcux + C::MCUS - 1) / C::MCUS;
+    const dim3 grid((unsigned)(tiles_x * g.mcuy)), block(C::THREADS);
+    switch (algo) {
+        case ALGO_REAL: hipLaunchKernelGGL((k_front<HS, VS, ALGO_REAL>), grid, block, 0, s, src, g, coef); break;
+        case ALGO_BIN: hipLaunchKernelGGL((k_front<HS, VS, ALGO_BIN>), grid, block, 0, s, src, g, coef); break;
+        case ALGO_REAL_STRICT:
+            hipLaunchKernelGGL((k_front<HS, VS, ALGO_REAL_STRICT>), grid, block, 0, s, src, g, coef);
+            break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_front(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s) {
+    // the fast path reads rows as dwords
+    if ((reinterpret_cast<uintptr_t>(src) & 3) || (g.stride & 3)) return hipErrorInvalidValue;
+    if (g.h == 2 && g.v == 2) return launch_front_hv<2, 2>(g, algo, src, coef, s);
+    if (g.h == 2 && g.v == 1) return launch_front_hv<2, 1>(g, algo, src, coef, s);
+    if (g.h == 1 && g.v == 1) return launch_front_hv<1, 1>(g, algo, src, coef, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace jpg

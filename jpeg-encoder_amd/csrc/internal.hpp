@@ -1,0 +1,73 @@
+// Internal declarations shared by the translation units of libjpeg_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace jpg {
+
+// Geometry of one image (or one MCU-row stripe of an image).
+//
+// Coefficient storage ("scan layout"): 8x8 blocks in the order the entropy
+// coder visits them -- MCUs row-major, inside an MCU the h*v luma blocks
+// row-major, then Cb, then Cr (src/jpeg/entropy_coding.rs:74-124) -- 64 int16
+// per block in zigzag order (src/jpeg/huffman_tables.rs:97-101), 128 bytes per
+// block.  The reference's row-major planes (src/pixel_matrix/block_iterator.rs:
+// 78-90) are a fixed permutation of this, produced on request by unscan().
+struct Geom {
+    int W, H;        // image size in pixels
+    int h, v;        // chroma subsampling factors (src/jpeg/sampling.rs:6-22)
+    int Wp, Hp;      // luma plane size, padded to the MCU (src/jpeg/jpeg_image.rs:36-49)
+    int Wc, Hc;      // chroma plane size (src/jpeg/sampling.rs:24-44); == Wp/h, Hp/v here
+    int mcux, mcuy;  // MCUs per row / column
+    int nb;          // blocks per MCU = h*v + 2
+    uint32_t stride; // bytes between BMP rows
+    int bottom_up;   // BMP row order (src/bmp/bmp_image.rs:65-70)
+    long long nblocks;
+};
+
+enum { ALGO_REAL = 0, ALGO_BIN = 1, ALGO_REAL_STRICT = 2 };
+
+// Entropy-stage geometry: one wavefront codes a "chunk" of 8 consecutive
+// blocks; a workgroup of 4 waves codes a "group" of 32 chunks.
+constexpr int CHUNK_BLOCKS = 8;
+constexpr int GROUP_CHUNKS = 32;
+constexpr int GROUP_BLOCKS = CHUNK_BLOCKS * GROUP_CHUNKS;
+// worst-case coded size of one block: DC 9+11 bits, 63 AC x (16+10) bits
+constexpr int MAX_BLOCK_BITS = 20 + 63 * 26;
+// byte-stuffing works on segments of this many unstuffed bytes
+constexpr int STUFF_SEG = 4096;
+
+struct EntropyBufs {
+    uint32_t *chunk_len;   // [nchunks] bits of each chunk
+    uint32_t *chunk_off;   // [nchunks] bit offset of the chunk inside its group
+    uint32_t *group_len;   // [ngroups]
+    uint64_t *group_base;  // [ngroups] bit offset of the group in the stream
+    uint64_t *totals;      // [0] total bits, [1] stuffed byte count, [2] unstuffed bytes consumed by stitch
+    int *error;            // sticky jpg_status raised by a kernel
+    uint32_t *bits;        // unstuffed MSB-first stream, as 32-bit words in memory byte order
+    size_t bits_cap;       // bytes
+    uint32_t *seg_cnt;     // [nseg_cap] 0xFF bytes per stuffing segment
+    uint64_t *seg_off;     // [nseg_cap] output byte offset of each segment
+    uint8_t *scan;         // stuffed stream
+    size_t scan_cap;
+    size_t nseg_cap;
+    uint8_t *tail;         // [1] bits of the dropped partial byte (stripes)
+};
+
+hipError_t launch_front(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s);
+hipError_t launch_color(const Geom &g, const uint8_t *src, uint8_t *y, uint8_t *cb, uint8_t *cr, hipStream_t s);
+hipError_t launch_downsample(const Geom &g, const uint8_t *cb, const uint8_t *cr, uint8_t *cb_out, uint8_t *cr_out,
+                             hipStream_t s);
+hipError_t launch_dct_planes(const Geom &g, int algo, const uint8_t *y, const uint8_t *cb, const uint8_t *cr,
+                             int16_t *coef, hipStream_t s);
+hipError_t launch_unscan(const Geom &g, const int16_t *coef, int comp, int16_t *plane, hipStream_t s);
+hipError_t launch_last_dc(const Geom &g, const int16_t *coef, int16_t *dc3, hipStream_t s);
+
+// pred: device pointer to 3 int16 DC predictors (Y, Cb, Cr) for the first blocks
+hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t *pred, const EntropyBufs &b,
+                          hipStream_t s);
+hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s);
+
+}  // namespace jpg

@@ -1,0 +1,247 @@
+// Per-thread 8x8 transforms: level shift, DCT (three variants), quantisation,
+// zigzag.  One thread owns one block; the 64 samples arrive as 16 dwords
+// (row r = px[2r], px[2r+1], bytes little-endian) and the 64 quantised
+// coefficients leave as 128 bytes in zigzag order at `slot` (LDS, 16-byte
+// aligned).  Everything is fully unrolled so that all array indices are
+// compile-time constants and the arrays live in registers.
+//
+// This translation unit is built with -ffp-contract=off: `a*b+c` never fuses.
+// Where a fused multiply-add is wanted it is written as fmaf().
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tables.h"
+
+namespace jpg {
+
+// cos(((2x+1)*u) as f32 * PI / 16) exactly as the reference evaluates it in f32
+// (src/jpeg/dct_quant.rs:222-223); index u*8+x.  glibc's cosf is correctly
+// rounded on these 64 arguments, so the bit patterns do not depend on the libm.
+constexpr uint32_t COS_BITS[64] = {
+    0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u,
+    0x3f7b14beu, 0x3f54db31u, 0x3f0e39d9u, 0x3e47c5bcu, 0xbe47c5c2u, 0xbf0e39dcu, 0xbf54db32u, 0xbf7b14bfu,
+    0x3f6c835eu, 0x3ec3ef15u, 0xbec3ef18u, 0xbf6c8360u, 0xbf6c835eu, 0xbec3ef0bu, 0x3ec3ef1bu, 0x3f6c835fu,
+    0x3f54db31u, 0xbe47c5c2u, 0xbf7b14bfu, 0xbf0e39d6u, 0x3f0e39ddu, 0x3f7b14beu, 0x3e47c5b1u, 0xbf54db34u,
+    0x3f3504f3u, 0xbf3504f3u, 0xbf3504f1u, 0x3f3504f7u, 0x3f3504f3u, 0xbf3504fbu, 0xbf3504efu, 0x3f3504f4u,
+    0x3f0e39d9u, 0xbf7b14bfu, 0x3e47c5c8u, 0x3f54db2du, 0xbf54db34u, 0xbe47c5bbu, 0x3f7b14bfu, 0xbf0e39e4u,
+    0x3ec3ef15u, 0xbf6c835eu, 0x3f6c835fu, 0xbec3ef25u, 0xbec3ef06u, 0x3f6c835bu, 0xbf6c8362u, 0x3ec3ef25u,
+    0x3e47c5bcu, 0xbf0e39d6u, 0x3f54db2du, 0xbf7b14bdu, 0x3f7b14c1u, 0xbf54db31u, 0x3f0e39e9u, 0xbe47c614u};
+
+__device__ __host__ constexpr float cosv(int u, int x) { return __builtin_bit_cast(float, COS_BITS[u * 8 + x]); }
+
+// (0.25 * alpha_u) * alpha_v in f32, alpha_0 = 1.0/SQRT_2 (src/jpeg/dct_quant.rs:196,228)
+__device__ __host__ constexpr float dct_scale(int u, int v) {
+    constexpr float inv_sqrt2 = 1.0f / 1.41421356237309505f;
+    float s = 0.25f * (u == 0 ? inv_sqrt2 : 1.0f);
+    return s * (v == 0 ? inv_sqrt2 : 1.0f);
+}
+
+template <bool CHROMA>
+__device__ __host__ constexpr int quant(int n) {
+    return CHROMA ? jpgtab::QT_CHROMA[n] : jpgtab::QT_LUMA[n];
+}
+
+// tables for the variant that loops over u at run time
+__device__ const float COS_DEV[64] = {
+    cosv(0, 0), cosv(0, 1), cosv(0, 2), cosv(0, 3), cosv(0, 4), cosv(0, 5), cosv(0, 6), cosv(0, 7),
+    cosv(1, 0), cosv(1, 1), cosv(1, 2), cosv(1, 3), cosv(1, 4), cosv(1, 5), cosv(1, 6), cosv(1, 7),
+    cosv(2, 0), cosv(2, 1), cosv(2, 2), cosv(2, 3), cosv(2, 4), cosv(2, 5), cosv(2, 6), cosv(2, 7),
+    cosv(3, 0), cosv(3, 1), cosv(3, 2), cosv(3, 3), cosv(3, 4), cosv(3, 5), cosv(3, 6), cosv(3, 7),
+    cosv(4, 0), cosv(4, 1), cosv(4, 2), cosv(4, 3), cosv(4, 4), cosv(4, 5), cosv(4, 6), cosv(4, 7),
+    cosv(5, 0), cosv(5, 1), cosv(5, 2), cosv(5, 3), cosv(5, 4), cosv(5, 5), cosv(5, 6), cosv(5, 7),
+    cosv(6, 0), cosv(6, 1), cosv(6, 2), cosv(6, 3), cosv(6, 4), cosv(6, 5), cosv(6, 6), cosv(6, 7),
+    cosv(7, 0), cosv(7, 1), cosv(7, 2), cosv(7, 3), cosv(7, 4), cosv(7, 5), cosv(7, 6), cosv(7, 7)};
+
+struct QuantF {
+    float q[2][64];
+    uint8_t zz[64];
+    constexpr QuantF() : q{}, zz{} {
+        for (int n = 0; n < 64; n++) {
+            q[0][n] = (float)jpgtab::QT_LUMA[n];
+            q[1][n] = (float)jpgtab::QT_CHROMA[n];
+            zz[n] = jpgtab::ZZ_OF_NATURAL.k[n];
+        }
+    }
+};
+__device__ const QuantF QUANT_DEV{};
+
+__device__ __forceinline__ float sample(const uint32_t (&px)[16], int r, int c) {
+    // level shift (src/jpeg/dct_quant.rs:63-65): n - 128, exact in f32
+    return (float)((px[2 * r + (c >> 2)] >> (8 * (c & 3))) & 0xffu) - 128.0f;
+}
+__device__ __forceinline__ int sample_i(const uint32_t (&px)[16], int r, int c) {
+    return (int)((px[2 * r + (c >> 2)] >> (8 * (c & 3))) & 0xffu) - 128;
+}
+
+// res[k] = quantised coefficient at zigzag position k; pack and store 128 bytes
+__device__ __forceinline__ void store_zigzag(const int (&res)[64], uint32_t *slot) {
+    uint4 *s4 = reinterpret_cast<uint4 *>(slot);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint4 w;
+        w.x = ((uint32_t)res[8 * i + 0] & 0xffffu) | ((uint32_t)res[8 * i + 1] << 16);
+        w.y = ((uint32_t)res[8 * i + 2] & 0xffffu) | ((uint32_t)res[8 * i + 3] << 16);
+        w.z = ((uint32_t)res[8 * i + 4] & 0xffffu) | ((uint32_t)res[8 * i + 5] << 16);
+        w.w = ((uint32_t)res[8 * i + 6] & 0xffffu) | ((uint32_t)res[8 * i + 7] << 16);
+        s4[i] = w;
+    }
+}
+
+// ((0.25*au*av*sum) / q) as i16 (src/jpeg/dct_quant.rs:227-230): one unfused
+// multiply, one correctly rounded divide, truncation toward zero.
+__device__ __forceinline__ int quantise_real(float sum, float scale, float q) {
+    float s = scale * sum;
+    float d = s / q;
+    return (int)d;
+}
+
+// --- separable f32 DCT ------------------------------------------------------
+// Same cosine table, same final expression; the 64-term sum of the reference
+// is regrouped as two 8-term FMA passes (rows, then columns).  The DC sum is
+// exact either way (all cosines 1.0, integer samples).
+template <bool CHROMA>
+__device__ __forceinline__ void transform_real(const uint32_t (&px)[16], uint32_t *slot) {
+    float tmp[64];  // tmp[x*8+v] = sum_y e[x][y] * cos(v,y)
+#pragma unroll
+    for (int x = 0; x < 8; x++) {
+        float e[8];
+#pragma unroll
+        for (int y = 0; y < 8; y++) e[y] = sample(px, x, y);
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int y = 0; y < 8; y++) acc = fmaf(e[y], cosv(v, y), acc);
+            tmp[x * 8 + v] = acc;
+        }
+    }
+    int res[64];
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int x = 0; x < 8; x++) acc = fmaf(cosv(u, x), tmp[x * 8 + v], acc);
+            const int n = u * 8 + v;
+            res[jpgtab::ZZ_OF_NATURAL.k[n]] = quantise_real(acc, dct_scale(u, v), (float)quant<CHROMA>(n));
+        }
+    }
+    store_zigzag(res, slot);
+}
+
+// --- the reference's own summation order, bit-exact -------------------------
+// sum over x (outer), y (inner) of (e*cos(u,x))*cos(v,y), accumulated left to
+// right in f32 with separate multiply and add (src/jpeg/dct_quant.rs:217-225).
+// The u loop stays rolled to bound code size; results go to LDS as int16.
+template <bool CHROMA>
+__device__ __forceinline__ void transform_real_strict(const uint32_t (&px)[16], uint32_t *slot) {
+    float e[64];
+#pragma unroll
+    for (int x = 0; x < 8; x++)
+#pragma unroll
+        for (int y = 0; y < 8; y++) e[x * 8 + y] = sample(px, x, y);
+    int16_t *s16 = reinterpret_cast<int16_t *>(slot);
+    const float inv_sqrt2 = 1.0f / 1.41421356237309505f;
+#pragma unroll 1
+    for (int u = 0; u < 8; u++) {
+        float cu[8];
+#pragma unroll
+        for (int x = 0; x < 8; x++) cu[x] = COS_DEV[u * 8 + x];
+        float t[64];
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+#pragma unroll
+            for (int y = 0; y < 8; y++) t[x * 8 + y] = e[x * 8 + y] * cu[x];
+        const float su = 0.25f * (u == 0 ? inv_sqrt2 : 1.0f);
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int x = 0; x < 8; x++)
+#pragma unroll
+                for (int y = 0; y < 8; y++) {
+                    float p = t[x * 8 + y] * cosv(v, y);
+                    sum = sum + p;
+                }
+            const float scale = su * (v == 0 ? inv_sqrt2 : 1.0f);
+            const int n = u * 8 + v;
+            int r = quantise_real(sum, scale, QUANT_DEV.q[CHROMA ? 1 : 0][n]);
+            s16[QUANT_DEV.zz[n]] = (int16_t)r;
+        }
+    }
+}
+
+// --- all-lifting binDCT-C (src/jpeg/dct_quant.rs:93-129) --------------------
+__device__ __forceinline__ void bin8(int &a0, int &a1, int &a2, int &a3, int &a4, int &a5, int &a6, int &a7) {
+    int x7_1 = a0 - a7, x0_1 = a0 - (x7_1 >> 1);
+    int x6_1 = a1 - a6, x1_1 = a1 - (x6_1 >> 1);
+    int x5_1 = a2 - a5, x2_1 = a2 - (x5_1 >> 1);
+    int x4_1 = a3 - a4, x3_1 = a3 - (x4_1 >> 1);
+    x6_1 = ((x5_1 * 3) >> 3) + x6_1;
+    x5_1 = ((x6_1 * 5) >> 3) - x5_1;
+    int x0_2 = x0_1 + x3_1, x3_2 = x0_1 - x3_1;
+    int x1_2 = x1_1 + x2_1, x2_2 = x1_1 - x2_1;
+    int x4_2 = x4_1 + x5_1, x5_2 = x4_1 - x5_1;
+    int x6_2 = x7_1 - x6_1, x7_2 = x7_1 + x6_1;
+    x4_2 = x4_2 - (x7_2 >> 3);
+    x0_2 = x0_2 + x1_2;
+    x1_2 = -x1_2 + (x0_2 >> 1);
+    x2_2 = x2_2 - ((x3_2 * 3) >> 3);
+    x3_2 = x3_2 + ((x2_2 * 3) >> 3);
+    x5_2 = x5_2 + ((x6_2 * 7) >> 3);
+    x6_2 = x6_2 - (x5_2 >> 1);
+    // output order of src/jpeg/dct_quant.rs:122-129
+    a0 = x0_2; a4 = x1_2; a6 = x2_2; a2 = x3_2;
+    a7 = x4_2; a5 = x5_2; a3 = x6_2; a1 = x7_2;
+}
+
+template <bool CHROMA>
+__device__ __forceinline__ void transform_bin(const uint32_t (&px)[16], uint32_t *slot) {
+    int a[64];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) a[r * 8 + c] = sample_i(px, r, c);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        bin8(a[i * 8 + 0], a[i * 8 + 1], a[i * 8 + 2], a[i * 8 + 3], a[i * 8 + 4], a[i * 8 + 5], a[i * 8 + 6],
+             a[i * 8 + 7]);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        bin8(a[0 * 8 + i], a[1 * 8 + i], a[2 * 8 + i], a[3 * 8 + i], a[4 * 8 + i], a[5 * 8 + i], a[6 * 8 + i],
+             a[7 * 8 + i]);
+    int res[64];
+#pragma unroll
+    for (int n = 0; n < 64; n++) {
+        // i32 / i32 truncating toward zero (src/jpeg/dct_quant.rs:182-186); the
+        // divisor is a compile-time constant, so this is a multiply-high.
+        res[jpgtab::ZZ_OF_NATURAL.k[n]] = a[n] / quant<CHROMA>(n);
+    }
+    store_zigzag(res, slot);
+}
+
+template <int ALGO, bool CHROMA>
+__device__ __forceinline__ void transform_block(const uint32_t (&px)[16], uint32_t *slot) {
+    if constexpr (ALGO == 0) transform_real<CHROMA>(px, slot);
+    else if constexpr (ALGO == 1) transform_bin<CHROMA>(px, slot);
+    else transform_real_strict<CHROMA>(px, slot);
+}
+
+// BT.601 full-range conversion in the reference's f32 evaluation order
+// (src/utils/colorspace.rs:5-15), `as u8` = truncate toward zero and saturate.
+__device__ __forceinline__ void rgb_to_ycbcr(float r, float g, float b, uint32_t &y, uint32_t &cb, uint32_t &cr) {
+    float fy = 0.299f * r + 0.587f * g;
+    fy = fy + 0.114f * b;
+    float fb = 128.0f - 0.168736f * r;
+    fb = fb - 0.331264f * g;
+    fb = fb + 0.5f * b;
+    float fr = 128.0f + 0.5f * r;
+    fr = fr - 0.418688f * g;
+    fr = fr - 0.081312f * b;
+    y = (uint32_t)min(max((int)fy, 0), 255);
+    cb = (uint32_t)min(max((int)fb, 0), 255);
+    cr = (uint32_t)min(max((int)fr, 0), 255);
+}
+
+}  // namespace jpg
