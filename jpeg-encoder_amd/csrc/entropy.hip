@@ -118,7 +118,9 @@ __global__ __launch_bounds__(256) void k_entropy(EntArgs a) {
         }
         int prevk = __shfl_up(hi, 1, 8);
         if (j == 0) prevk = -1;
-        const uint32_t blk_end = g < 7 ? (uint32_t)__shfl(base, (g + 1) * 8) : total;
+        // every lane must take part in the shuffle: an inactive source lane reads as 0
+        const uint32_t next_base = (uint32_t)__shfl(base, ((g + 1) * 8) & 63);
+        const uint32_t blk_end = g < 7 ? next_base : total;
         uint32_t pos = base;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
