@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X JPEG encode path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json config 3): 7680x4320 24-bit BMP rows, 4:2:0, real-dct.
+One step = every rank encodes its own batch of `--batch` distinct synthetic
+8K images (device-resident BMP rows -> stuffed JPEG scan bytes in HBM): colour
+conversion + subsampling + DCT + quantisation (one fused kernel), entropy
+coding and byte stuffing.  Images are independent, so ranks share nothing
+(weak scaling, no data-path collective).  Prints ONE JSON line on rank 0.
+
+The batch rotates over distinct images so that the inputs of consecutive
+encodes do not sit in the 256 MiB Infinity Cache.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=7680)
+    ap.add_argument("--height", type=int, default=4320)
+    ap.add_argument("--ratio", default="4:2:0")
+    ap.add_argument("--dct-algorithm", default="real-dct")
+    ap.add_argument("--batch", type=int, default=4, help="distinct images per rank per step")
+    ap.add_argument("--noise", action="store_true", help="uniform-noise images (entropy stress)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-iters", type=int, default=40, help="front-kernel launches for the roofline figure")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The CPU oracle (restatement of the reference, cosine evaluated per term as the reference does,
+    3 DCT threads like src/jpeg/dct_quant.rs:29-60) on a bounded sample of the same workload."""
+    from oracle import refcpu
+    import jpeg_encoder_amd as J
+    refcpu.build()
+    w, h = min(args.width, 3840), min(args.height, 2160)
+    ratio = tuple(int(x) for x in args.ratio.split(":"))
+    algo = refcpu.BIN if args.dct_algorithm == "bin-dct" else refcpu.REAL
+    rows = J.host.synth_bgr(w, h, seed=1000, noise_only=args.noise)
+    t0 = time.perf_counter()
+    im = refcpu.RefImage.from_bgr(rows, w, h, rows.shape[1], ratio, algo)
+    im.chrominance_downsampling(threads=2)
+    im.dct_and_quantization(cos_mode=refcpu.COS_CALL, threads=3)
+    im.generate_entropy_encoded_data()
+    im.stuffed_scan()
+    dt = time.perf_counter() - t0
+    return {"value": round(w * h / 1e6 / dt, 4), "unit": "MP/s", "cores": 3, "kind": "port",
+            "sample": "one %dx%d synthetic image, %s %s, pixels already in memory, no file I/O; %.1f s" %
+                      (w, h, args.ratio, args.dct_algorithm, dt),
+            "host_cores_available": os.cpu_count()}
+
+
+def pmc_traffic(workload):
+    """HBM bytes per front-kernel launch from a committed rocprofv3 --pmc summary, if one matches."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*front_pmc*.json"))):
+        try:
+            d = json.load(open(p))
+            if d.get("workload") == workload and d.get("hbm_bytes_per_launch"):
+                best = d["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+    return best
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import jpeg_encoder_amd as J
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    ratio = tuple(int(x) for x in args.ratio.split(":"))
+    W, H = args.width, args.height
+    stride = J.host.bmp_stride(W)
+    # distinct images per rank: seed = config << 32 | image index
+    imgs = []
+    for i in range(args.batch):
+        rows = J.host.synth_bgr(W, H, seed=(3 << 32) | (rank * args.batch + i), noise_only=args.noise)
+        imgs.append(torch.from_numpy(rows).cuda())
+    torch.cuda.synchronize()
+
+    enc = J.Encoder(ratio, args.dct_algorithm, device=local)
+
+    def step():
+        for t in imgs:
+            enc.encode_device_async(t.data_ptr(), W, H, stride, True)
+        return enc.finish()
+
+    for _ in range(args.warmup):
+        nbits, scan_len = step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        enc.sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nbits, scan_len = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline of the dominant kernel: fused colour+subsample+DCT+quant ----
+    roof = None
+    if rank == 0:
+        s = torch.cuda.ExternalStream(enc.stream, device=torch.device("cuda", local))
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for k in range(4):
+            enc.front_device(imgs[k % len(imgs)].data_ptr(), W, H, stride, True)
+        enc.sync()
+        n = args.kernel_iters
+        ev0.record(s)
+        for k in range(n):
+            enc.front_device(imgs[k % len(imgs)].data_ptr(), W, H, stride, True)
+        ev1.record(s)
+        enc.sync()
+        kms = ev0.elapsed_time(ev1) / n
+        alg = enc.front_bytes()
+        achieved = alg / (kms * 1e-3) / 1e9
+        workload = "%dx%d %s %s" % (W, H, args.ratio, args.dct_algorithm)
+        roof = {"bound": "hbm", "kernel": "k_front", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(workload),
+                "algorithmic_bytes": alg, "kernel_ms": round(kms, 5)}
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        mp = W * H / 1e6
+        total_mp = mp * args.batch * world * args.steps
+        out = {
+            "metric": "encode megapixels/sec (8K 4:2:0 real-dct, device-resident BMP rows -> stuffed JPEG scan)",
+            "value": round(total_mp / dt, 1),
+            "unit": "MP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if args.dct_algorithm.startswith("real") else "int32",
+            "data": "synthetic" + (" (uniform noise)" if args.noise else ""),
+            "config": {"workload": "%dx%d BMP, %s, %s" % (W, H, args.ratio, args.dct_algorithm),
+                       "images_per_rank_per_step": args.batch, "global_batch": args.batch * world,
+                       "parallelism": "image-sharded x%d" % world, "scan_bytes_last_image": int(scan_len),
+                       "bits_per_pixel": round(nbits / (W * H), 4)},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

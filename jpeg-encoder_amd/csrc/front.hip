@@ -24,6 +24,7 @@ namespace jpg {
 
 constexpr int TILE_W = 512;     // pixels per tile row
 constexpr int OUT_STRIDE = 144; // bytes between parked blocks in LDS (128 + 16: conflict-free b128 access)
+constexpr int THREADS = 256;
 
 template <int HS, int VS>
 struct TileCfg {
@@ -32,18 +33,60 @@ struct TileCfg {
     static constexpr int TILE_H = 8 * VS;                     // image rows per tile
     static constexpr int YWAVES = VS;                         // 64 luma blocks per block row
     static constexpr int CWAVES = (2 * MCUS) / 64;            // chroma blocks: MCUS per component
-    static constexpr int THREADS = 64 * (YWAVES + CWAVES);
     static constexpr int CW = TILE_W / HS;                    // chroma samples per tile row
     static constexpr int BLOCKS = MCUS * NBLK;
+    static constexpr int ITEMS = (TILE_W / 4) * 8;            // groups of 4 pixels x VS rows
+    static constexpr int ROUNDS = ITEMS / THREADS;            // items per thread in a full tile
+    static constexpr int PLANE_BYTES = TILE_H * TILE_W + 2 * 8 * CW;
+    static constexpr int OUT_BYTES = BLOCKS * OUT_STRIDE;
+    static constexpr int LDS_BYTES = PLANE_BYTES > OUT_BYTES ? PLANE_BYTES : OUT_BYTES;
+    static_assert(YWAVES + CWAVES <= THREADS / 64, "one thread per block");
+    static_assert(ITEMS % THREADS == 0, "whole rounds");
 };
 
-template <int HS, int VS, int ALGO>
-__global__ __launch_bounds__((TileCfg<HS, VS>::THREADS)) void k_front(const uint8_t *__restrict__ src, Geom g,
-                                                                      int16_t *__restrict__ coef) {
+// 4 pixels of one row: 12 bytes B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3 -> packed Y, Cb, Cr bytes
+__device__ __forceinline__ void convert4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t &y4, uint32_t (&cb)[4],
+                                         uint32_t (&cr)[4]) {
+    const f2 r01 = {(float)((d0 >> 16) & 0xff), (float)((d1 >> 8) & 0xff)};
+    const f2 g01 = {(float)((d0 >> 8) & 0xff), (float)(d1 & 0xff)};
+    const f2 b01 = {(float)(d0 & 0xff), (float)(d0 >> 24)};
+    const f2 r23 = {(float)(d2 & 0xff), (float)(d2 >> 24)};
+    const f2 g23 = {(float)(d1 >> 24), (float)((d2 >> 16) & 0xff)};
+    const f2 b23 = {(float)((d1 >> 16) & 0xff), (float)((d2 >> 8) & 0xff)};
+    f2 y01, cb01, cr01, y23, cb23, cr23;
+    rgb_to_ycbcr2(r01, g01, b01, y01, cb01, cr01);
+    rgb_to_ycbcr2(r23, g23, b23, y23, cb23, cr23);
+    // `as u8`: truncation; the values are within [0, 256) by construction
+    y4 = (uint32_t)y01.x | ((uint32_t)y01.y << 8) | ((uint32_t)y23.x << 16) | ((uint32_t)y23.y << 24);
+    cb[0] = (uint32_t)cb01.x; cb[1] = (uint32_t)cb01.y; cb[2] = (uint32_t)cb23.x; cb[3] = (uint32_t)cb23.y;
+    cr[0] = (uint32_t)cr01.x; cr[1] = (uint32_t)cr01.y; cr[2] = (uint32_t)cr23.x; cr[3] = (uint32_t)cr23.y;
+}
+
+template <int HS, int VS>
+__device__ __forceinline__ void store_chroma(uint8_t *sCb, uint8_t *sCr, int iy, int ix, const uint32_t (&cbs)[4],
+                                             const uint32_t (&crs)[4]) {
     using C = TileCfg<HS, VS>;
-    __shared__ __attribute__((aligned(16))) uint8_t sY[C::TILE_H][TILE_W];
-    __shared__ __attribute__((aligned(16))) uint8_t sC[2][8][C::CW];
-    __shared__ __attribute__((aligned(16))) uint8_t sOut[C::BLOCKS * OUT_STRIDE];
+    // box average, floor(sum / (h*v)) (src/jpeg/sampling.rs:66-73)
+    if constexpr (HS == 2) {
+        const uint32_t b0 = (cbs[0] + cbs[1]) / (2 * VS), b1 = (cbs[2] + cbs[3]) / (2 * VS);
+        const uint32_t r0 = (crs[0] + crs[1]) / (2 * VS), r1 = (crs[2] + crs[3]) / (2 * VS);
+        *reinterpret_cast<uint16_t *>(&sCb[iy * C::CW + 2 * ix]) = (uint16_t)(b0 | (b1 << 8));
+        *reinterpret_cast<uint16_t *>(&sCr[iy * C::CW + 2 * ix]) = (uint16_t)(r0 | (r1 << 8));
+    } else {
+        *reinterpret_cast<uint32_t *>(&sCb[iy * C::CW + 4 * ix]) = cbs[0] | (cbs[1] << 8) | (cbs[2] << 16) | (cbs[3] << 24);
+        *reinterpret_cast<uint32_t *>(&sCr[iy * C::CW + 4 * ix]) = crs[0] | (crs[1] << 8) | (crs[2] << 16) | (crs[3] << 24);
+    }
+}
+
+template <int HS, int VS, int ALGO>
+__global__ __launch_bounds__(THREADS) void k_front(const uint8_t *__restrict__ src, Geom g,
+                                                   int16_t *__restrict__ coef) {
+    using C = TileCfg<HS, VS>;
+    // Y plane, then Cb, Cr planes of the tile; phase B reuses the space for the finished blocks
+    __shared__ __attribute__((aligned(16))) uint8_t lds[C::LDS_BYTES];
+    uint8_t *sY = lds;
+    uint8_t *sCb = lds + C::TILE_H * TILE_W;
+    uint8_t *sCr = sCb + 8 * C::CW;
 
     const int tiles_x = (g.mcux + C::MCUS - 1) / C::MCUS;
     const int tile_x = blockIdx.x % tiles_x;
@@ -55,86 +98,102 @@ __global__ __launch_bounds__((TileCfg<HS, VS>::THREADS)) void k_front(const uint
     const int tid = threadIdx.x;
 
     // ---------------- phase A: colour conversion + chroma average ----------
-    const int items_x = mcus * 2 * HS;                        // groups of 4 pixels across the tile
-    const bool rows_inside = (y0 + C::TILE_H <= g.H);
-    for (int it = tid; it < items_x * 8; it += C::THREADS) {
-        const int ix = it % items_x;
-        const int iy = it / items_x;                          // chroma row inside the tile, 0..7
-        const int x = x0 + 4 * ix;
-        uint32_t cbs[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
+    if (mcus == C::MCUS && x0 + TILE_W <= g.W && y0 + C::TILE_H <= g.H) {
+        // interior tile: every thread owns ROUNDS items; all loads are issued before the arithmetic
+        uint32_t d[C::ROUNDS][VS][3];
+        const int ix = tid & 127;
 #pragma unroll
-        for (int r = 0; r < VS; r++) {
-            const int ly = iy * VS + r;
-            const int y = y0 + ly;
-            uint32_t yy[4] = {0, 0, 0, 0}, cb[4] = {0, 0, 0, 0}, cr[4] = {0, 0, 0, 0};
-            if (rows_inside && x + 4 <= g.W) {
+        for (int k = 0; k < C::ROUNDS; k++) {
+            const int iy = 2 * k + (tid >> 7);
+#pragma unroll
+            for (int r = 0; r < VS; r++) {
+                const int y = y0 + iy * VS + r;
                 const size_t row = (size_t)(g.bottom_up ? g.H - 1 - y : y) * g.stride;
-                const uint32_t *p = reinterpret_cast<const uint32_t *>(src + row + (size_t)3 * x);
-                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-                // bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-                rgb_to_ycbcr((float)((d0 >> 16) & 0xff), (float)((d0 >> 8) & 0xff), (float)(d0 & 0xff), yy[0], cb[0], cr[0]);
-                rgb_to_ycbcr((float)((d1 >> 8) & 0xff), (float)(d1 & 0xff), (float)(d0 >> 24), yy[1], cb[1], cr[1]);
-                rgb_to_ycbcr((float)(d2 & 0xff), (float)(d1 >> 24), (float)((d1 >> 16) & 0xff), yy[2], cb[2], cr[2]);
-                rgb_to_ycbcr((float)(d2 >> 24), (float)((d2 >> 16) & 0xff), (float)((d2 >> 8) & 0xff), yy[3], cb[3], cr[3]);
-            } else if (y < g.H) {
-                // image edge: samples outside W x H stay 0 in all three planes
-                // (zero-filled planes of src/jpeg/jpeg_image.rs:59-70)
-                const uint8_t *p = src + (size_t)(g.bottom_up ? g.H - 1 - y : y) * g.stride;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (x + k < g.W) {
-                        const uint8_t *q = p + (size_t)3 * (x + k);
-                        rgb_to_ycbcr((float)q[2], (float)q[1], (float)q[0], yy[k], cb[k], cr[k]);
-                    }
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(src + row + (size_t)3 * (x0 + 4 * ix));
+                d[k][r][0] = p[0]; d[k][r][1] = p[1]; d[k][r][2] = p[2];
             }
-            *reinterpret_cast<uint32_t *>(&sY[ly][4 * ix]) = yy[0] | (yy[1] << 8) | (yy[2] << 16) | (yy[3] << 24);
-#pragma unroll
-            for (int k = 0; k < 4; k++) { cbs[k] += cb[k]; crs[k] += cr[k]; }
         }
-        // box average, floor(sum / (h*v)) (src/jpeg/sampling.rs:66-73)
-        if constexpr (HS == 2) {
-            const uint32_t b0 = (cbs[0] + cbs[1]) / (2 * VS), b1 = (cbs[2] + cbs[3]) / (2 * VS);
-            const uint32_t r0 = (crs[0] + crs[1]) / (2 * VS), r1 = (crs[2] + crs[3]) / (2 * VS);
-            *reinterpret_cast<uint16_t *>(&sC[0][iy][2 * ix]) = (uint16_t)(b0 | (b1 << 8));
-            *reinterpret_cast<uint16_t *>(&sC[1][iy][2 * ix]) = (uint16_t)(r0 | (r1 << 8));
-        } else {
-            *reinterpret_cast<uint32_t *>(&sC[0][iy][4 * ix]) = cbs[0] | (cbs[1] << 8) | (cbs[2] << 16) | (cbs[3] << 24);
-            *reinterpret_cast<uint32_t *>(&sC[1][iy][4 * ix]) = crs[0] | (crs[1] << 8) | (crs[2] << 16) | (crs[3] << 24);
+#pragma unroll
+        for (int k = 0; k < C::ROUNDS; k++) {
+            const int iy = 2 * k + (tid >> 7);
+            uint32_t cbs[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < VS; r++) {
+                uint32_t y4, cb[4], cr[4];
+                convert4(d[k][r][0], d[k][r][1], d[k][r][2], y4, cb, cr);
+                *reinterpret_cast<uint32_t *>(&sY[(iy * VS + r) * TILE_W + 4 * ix]) = y4;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { cbs[q] += cb[q]; crs[q] += cr[q]; }
+            }
+            store_chroma<HS, VS>(sCb, sCr, iy, ix, cbs, crs);
+        }
+    } else {
+        // edge tile: samples outside W x H stay 0 in all three planes
+        // (zero-filled planes of src/jpeg/jpeg_image.rs:59-70)
+        const int items_x = mcus * 2 * HS;
+        for (int it = tid; it < items_x * 8; it += THREADS) {
+            const int ix = it % items_x, iy = it / items_x;
+            const int x = x0 + 4 * ix;
+            uint32_t cbs[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < VS; r++) {
+                const int ly = iy * VS + r, y = y0 + ly;
+                uint32_t yy[4] = {0, 0, 0, 0};
+                if (y < g.H) {
+                    const uint8_t *p = src + (size_t)(g.bottom_up ? g.H - 1 - y : y) * g.stride;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (x + q < g.W) {
+                            const uint8_t *c = p + (size_t)3 * (x + q);
+                            uint32_t cb, cr;
+                            rgb_to_ycbcr((float)c[2], (float)c[1], (float)c[0], yy[q], cb, cr);
+                            cbs[q] += cb;
+                            crs[q] += cr;
+                        }
+                }
+                *reinterpret_cast<uint32_t *>(&sY[ly * TILE_W + 4 * ix]) = yy[0] | (yy[1] << 8) | (yy[2] << 16) | (yy[3] << 24);
+            }
+            store_chroma<HS, VS>(sCb, sCr, iy, ix, cbs, crs);
         }
     }
     __syncthreads();
 
     // ---------------- phase B: one thread per 8x8 block ---------------------
     const int wave = tid >> 6, lane = tid & 63;
+    uint32_t px[16];
+    int bi = -1;                                               // block index inside the tile, scan order
     if (wave < C::YWAVES) {
         // luma: block row `wave`, block column `lane` of the tile
         const int m = lane / HS;                               // MCU inside the tile
         if (m < mcus) {
-            uint32_t px[16];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const uint2 d = *reinterpret_cast<const uint2 *>(&sY[wave * 8 + r][lane * 8]);
-                px[2 * r] = d.x;
-                px[2 * r + 1] = d.y;
+                const uint2 v = *reinterpret_cast<const uint2 *>(&sY[(wave * 8 + r) * TILE_W + lane * 8]);
+                px[2 * r] = v.x;
+                px[2 * r + 1] = v.y;
             }
-            const int bi = m * C::NBLK + wave * HS + (lane % HS);
-            transform_block<ALGO, false>(px, reinterpret_cast<uint32_t *>(&sOut[bi * OUT_STRIDE]));
+            bi = m * C::NBLK + wave * HS + (lane % HS);
         }
-    } else {
+    } else if (wave < C::YWAVES + C::CWAVES) {
         const int ci = (wave - C::YWAVES) * 64 + lane;         // 0 .. 2*MCUS-1
         const int comp = ci / C::MCUS;                         // 0 Cb, 1 Cr
         const int m = ci % C::MCUS;
         if (m < mcus) {
-            uint32_t px[16];
+            const uint8_t *pl = comp ? sCr : sCb;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const uint2 d = *reinterpret_cast<const uint2 *>(&sC[comp][r][m * 8]);
-                px[2 * r] = d.x;
-                px[2 * r + 1] = d.y;
+                const uint2 v = *reinterpret_cast<const uint2 *>(&pl[r * C::CW + m * 8]);
+                px[2 * r] = v.x;
+                px[2 * r + 1] = v.y;
             }
-            const int bi = m * C::NBLK + HS * VS + comp;
-            transform_block<ALGO, true>(px, reinterpret_cast<uint32_t *>(&sOut[bi * OUT_STRIDE]));
+            bi = m * C::NBLK + HS * VS + comp;
         }
+    }
+    __syncthreads();   // every sample is in registers: the planes' space becomes the output staging area
+    if (bi >= 0) {
+        uint32_t *slot = reinterpret_cast<uint32_t *>(&lds[bi * OUT_STRIDE]);
+        if (wave < C::YWAVES) transform_block<ALGO, false>(px, slot);
+        else transform_block<ALGO, true>(px, slot);
     }
     __syncthreads();
 
@@ -142,15 +201,15 @@ __global__ __launch_bounds__((TileCfg<HS, VS>::THREADS)) void k_front(const uint
     const size_t first_block = ((size_t)tile_y * g.mcux + mcu0) * C::NBLK;
     uint4 *dst = reinterpret_cast<uint4 *>(coef + first_block * 64);
     const int units = mcus * C::NBLK * 8;                      // 16-byte pieces
-    for (int u = tid; u < units; u += C::THREADS)
-        dst[u] = *reinterpret_cast<const uint4 *>(&sOut[(u >> 3) * OUT_STRIDE + (u & 7) * 16]);
+    for (int u = tid; u < units; u += THREADS)
+        dst[u] = *reinterpret_cast<const uint4 *>(&lds[(u >> 3) * OUT_STRIDE + (u & 7) * 16]);
 }
 
 template <int HS, int VS>
 static hipError_t launch_front_hv(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s) {
     using C = TileCfg<HS, VS>;
     const int tiles_x = (g.mcux + C::MCUS - 1) / C::MCUS;
-    const dim3 grid((unsigned)(tiles_x * g.mcuy)), block(C::THREADS);
+    const dim3 grid((unsigned)(tiles_x * g.mcuy)), block(THREADS);
     switch (algo) {
         case ALGO_REAL: hipLaunchKernelGGL((k_front<HS, VS, ALGO_REAL>), grid, block, 0, s, src, g, coef); break;
         case ALGO_BIN: hipLaunchKernelGGL((k_front<HS, VS, ALGO_BIN>), grid, block, 0, s, src, g, coef); break;

@@ -96,35 +96,79 @@ __device__ __forceinline__ int quantise_real(float sum, float scale, float q) {
 }
 
 // --- separable f32 DCT ------------------------------------------------------
-// Same cosine table, same final expression; the 64-term sum of the reference
-// is regrouped as two 8-term FMA passes (rows, then columns).  The DC sum is
-// exact either way (all cosines 1.0, integer samples).
+// Same cosine table and the same final expression as the reference; the
+// 64-term sum is regrouped as two 8-point passes (rows, then columns), each
+// split into its even and odd half (cos(v,7-y) = +-cos(v,y)), and evaluated
+// with packed FMAs on pairs of outputs.  The DC sum stays exact (all cosines
+// 1.0, integer samples).  Quantised values may differ from the reference's
+// summation order by +-1 where a quotient sits on a truncation boundary.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float x) { return (f2){x, x}; }
+__device__ __host__ constexpr float rcp_rn(int q) { return 1.0f / (float)q; }  // RN(1/q), folded at compile time
+
+// RN(s / q) for a compile-time divisor pair: q0 = s*z, r = s - q0*q (exact in
+// an FMA), d = q0 + r*z with z = RN(1/q).  Bit-identical to the IEEE quotient
+// for every divisor in the two tables (checked exhaustively by
+// tools/check_divide.c); then `as i16` = truncation toward zero.
+__device__ __forceinline__ void quantise_pair(f2 sum, f2 scale, f2 q, f2 z, int &n0, int &n1) {
+    const f2 s = scale * sum;
+    const f2 q0 = s * z;
+    const f2 r = pk_fma(-q0, q, s);
+    const f2 d = pk_fma(r, z, q0);
+    n0 = (int)d.x;
+    n1 = (int)d.y;
+}
+
+// 8-point pass, inputs a0..a7 (pairs of independent lanes), outputs o[v]
+// o[v] = sum_i cos(v,i) * (a_i +- a_(7-i)), i < 4
+__device__ __forceinline__ void dct8_pairs(const f2 (&a)[8], f2 (&o)[8]) {
+    const f2 s0 = a[0] + a[7], s1 = a[1] + a[6], s2 = a[2] + a[5], s3 = a[3] + a[4];
+    const f2 d0 = a[0] - a[7], d1 = a[1] - a[6], d2 = a[2] - a[5], d3 = a[3] - a[4];
+#pragma unroll
+    for (int v = 0; v < 8; v += 2)
+        o[v] = pk_fma(splat(cosv(v, 3)), s3, pk_fma(splat(cosv(v, 2)), s2, pk_fma(splat(cosv(v, 1)), s1, splat(cosv(v, 0)) * s0)));
+#pragma unroll
+    for (int v = 1; v < 8; v += 2)
+        o[v] = pk_fma(splat(cosv(v, 3)), d3, pk_fma(splat(cosv(v, 2)), d2, pk_fma(splat(cosv(v, 1)), d1, splat(cosv(v, 0)) * d0)));
+}
+
 template <bool CHROMA>
 __device__ __forceinline__ void transform_real(const uint32_t (&px)[16], uint32_t *slot) {
-    float tmp[64];  // tmp[x*8+v] = sum_y e[x][y] * cos(v,y)
+    // row pass on pairs of rows: t[p][v] = (tmp[2p][v], tmp[2p+1][v])
+    f2 t[4][8];
 #pragma unroll
-    for (int x = 0; x < 8; x++) {
-        float e[8];
+    for (int p = 0; p < 4; p++) {
+        f2 e[8];
 #pragma unroll
-        for (int y = 0; y < 8; y++) e[y] = sample(px, x, y);
-#pragma unroll
-        for (int v = 0; v < 8; v++) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int y = 0; y < 8; y++) acc = fmaf(e[y], cosv(v, y), acc);
-            tmp[x * 8 + v] = acc;
+        for (int y = 0; y < 8; y++) {
+            e[y].x = (float)((px[4 * p + (y >> 2)] >> (8 * (y & 3))) & 0xffu);
+            e[y].y = (float)((px[4 * p + 2 + (y >> 2)] >> (8 * (y & 3))) & 0xffu);
         }
+        dct8_pairs(e, t[p]);
     }
+    // column pass on pairs of columns (v, v+1): a[x] = (tmp[x][v], tmp[x][v+1])
     int res[64];
 #pragma unroll
-    for (int v = 0; v < 8; v++) {
+    for (int v = 0; v < 8; v += 2) {
+        f2 a[8], o[8];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            a[2 * p] = (f2){t[p][v].x, t[p][v + 1].x};
+            a[2 * p + 1] = (f2){t[p][v].y, t[p][v + 1].y};
+        }
+        dct8_pairs(a, o);
+        // level shift (src/jpeg/dct_quant.rs:63-65): subtracting 128 from every
+        // sample moves only the DC sum, by exactly 64*128
+        if (v == 0) o[0].x -= 8192.0f;
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int x = 0; x < 8; x++) acc = fmaf(cosv(u, x), tmp[x * 8 + v], acc);
-            const int n = u * 8 + v;
-            res[jpgtab::ZZ_OF_NATURAL.k[n]] = quantise_real(acc, dct_scale(u, v), (float)quant<CHROMA>(n));
+            const int n0 = u * 8 + v, n1 = n0 + 1;
+            const f2 scale = {dct_scale(u, v), dct_scale(u, v + 1)};
+            const f2 q = {(float)quant<CHROMA>(n0), (float)quant<CHROMA>(n1)};
+            const f2 z = {rcp_rn(quant<CHROMA>(n0)), rcp_rn(quant<CHROMA>(n1))};
+            quantise_pair(o[u], scale, q, z, res[jpgtab::ZZ_OF_NATURAL.k[n0]], res[jpgtab::ZZ_OF_NATURAL.k[n1]]);
         }
     }
     store_zigzag(res, slot);
@@ -242,6 +286,19 @@ __device__ __forceinline__ void rgb_to_ycbcr(float r, float g, float b, uint32_t
     y = (uint32_t)min(max((int)fy, 0), 255);
     cb = (uint32_t)min(max((int)fb, 0), 255);
     cr = (uint32_t)min(max((int)fr, 0), 255);
+}
+
+
+// the same on two pixels at once (packed f32; products and sums stay unfused)
+__device__ __forceinline__ void rgb_to_ycbcr2(f2 r, f2 g, f2 b, f2 &y, f2 &cb, f2 &cr) {
+    y = 0.299f * r + 0.587f * g;
+    y = y + 0.114f * b;
+    cb = 128.0f - 0.168736f * r;
+    cb = cb - 0.331264f * g;
+    cb = cb + 0.5f * b;
+    cr = 128.0f + 0.5f * r;
+    cr = cr - 0.418688f * g;
+    cr = cr - 0.081312f * b;
 }
 
 }  // namespace jpg
