@@ -22,7 +22,10 @@ CXX = os.environ.get("CXX") or shutil.which("g++") or "g++"
 
 # -ffp-contract=off: the reference's f32 arithmetic is never fused; fused
 # multiply-adds are written explicitly (fmaf) where they are wanted.
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+# -fno-slp-vectorize: packed f32 instructions have no throughput advantage on
+# gfx950 (a wave64 v_pk_fma_f32 takes twice the cycles of v_fma_f32) and the
+# vectoriser pays for them with register shuffles.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 HIP_SOURCES = ["front.hip", "staged.hip", "entropy.hip", "api.hip"]

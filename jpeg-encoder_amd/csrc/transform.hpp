@@ -87,6 +87,26 @@ __device__ __forceinline__ void store_zigzag(const int (&res)[64], uint32_t *slo
     }
 }
 
+// place quantised value n at zigzag position K of the packed block w[32];
+// `first` tells whether the other half of that dword is still unwritten
+template <int K>
+__device__ __forceinline__ void put16(uint32_t (&w)[32], int n, bool first) {
+    if (K & 1) w[K >> 1] = first ? ((uint32_t)n << 16) : (w[K >> 1] | ((uint32_t)n << 16));
+    else w[K >> 1] = first ? ((uint32_t)n & 0xffffu) : (w[K >> 1] | ((uint32_t)n & 0xffffu));
+}
+
+// same with the position as a (compile-time foldable) argument
+__device__ __forceinline__ void put16_rt(uint32_t (&w)[32], int k, int n, bool first) {
+    const uint32_t half = (k & 1) ? ((uint32_t)n << 16) : ((uint32_t)n & 0xffffu);
+    w[k >> 1] = first ? half : (w[k >> 1] | half);
+}
+
+__device__ __forceinline__ void store_packed(const uint32_t (&w)[32], uint32_t *slot) {
+    uint4 *s4 = reinterpret_cast<uint4 *>(slot);
+#pragma unroll
+    for (int i = 0; i < 8; i++) s4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
 // ((0.25*au*av*sum) / q) as i16 (src/jpeg/dct_quant.rs:227-230): one unfused
 // multiply, one correctly rounded divide, truncation toward zero.
 __device__ __forceinline__ int quantise_real(float sum, float scale, float q) {
@@ -96,82 +116,78 @@ __device__ __forceinline__ int quantise_real(float sum, float scale, float q) {
 }
 
 // --- separable f32 DCT ------------------------------------------------------
-// Same cosine table and the same final expression as the reference; the
-// 64-term sum is regrouped as two 8-point passes (rows, then columns), each
-// split into its even and odd half (cos(v,7-y) = +-cos(v,y)), and evaluated
-// with packed FMAs on pairs of outputs.  The DC sum stays exact (all cosines
-// 1.0, integer samples).  Quantised values may differ from the reference's
+// Same cosine table as the reference; the 64-term sum is regrouped as two
+// 8-point passes (rows, then columns).  Each pass splits into an even half on
+// a_i + a_(7-i) and an odd half on a_i - a_(7-i) (cos(v,7-i) = +-cos(v,i)), and
+// the even half once more (v = 0,4 from the sums, v = 2,6 from the
+// differences).  35 operations per pass instead of 64.  The DC path
+// (v = 0, u = 0) only adds integers and is exact, and the DC coefficient is
+// quantised with the reference's own two-step expression, so flat blocks come
+// out identical.  Other coefficients may differ from the reference's
 // summation order by +-1 where a quotient sits on a truncation boundary.
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 splat(float x) { return (f2){x, x}; }
 __device__ __host__ constexpr float rcp_rn(int q) { return 1.0f / (float)q; }  // RN(1/q), folded at compile time
 
-// RN(s / q) for a compile-time divisor pair: q0 = s*z, r = s - q0*q (exact in
-// an FMA), d = q0 + r*z with z = RN(1/q).  Bit-identical to the IEEE quotient
-// for every divisor in the two tables (checked exhaustively by
-// tools/check_divide.c); then `as i16` = truncation toward zero.
-__device__ __forceinline__ void quantise_pair(f2 sum, f2 scale, f2 q, f2 z, int &n0, int &n1) {
-    const f2 s = scale * sum;
-    const f2 q0 = s * z;
-    const f2 r = pk_fma(-q0, q, s);
-    const f2 d = pk_fma(r, z, q0);
-    n0 = (int)d.x;
-    n1 = (int)d.y;
+// RN(s / q) for a compile-time divisor: q0 = s*z, r = s - q0*q (exact in an
+// FMA), d = q0 + r*z with z = RN(1/q).  Bit-identical to the IEEE quotient for
+// every divisor in the two tables (checked exhaustively by tools/check_divide.c).
+__device__ __forceinline__ float div_const(float s, float q, float z) {
+    const float q0 = s * z;
+    const float r = fmaf(-q0, q, s);
+    return fmaf(r, z, q0);
 }
 
-// 8-point pass, inputs a0..a7 (pairs of independent lanes), outputs o[v]
-// o[v] = sum_i cos(v,i) * (a_i +- a_(7-i)), i < 4
-__device__ __forceinline__ void dct8_pairs(const f2 (&a)[8], f2 (&o)[8]) {
-    const f2 s0 = a[0] + a[7], s1 = a[1] + a[6], s2 = a[2] + a[5], s3 = a[3] + a[4];
-    const f2 d0 = a[0] - a[7], d1 = a[1] - a[6], d2 = a[2] - a[5], d3 = a[3] - a[4];
-#pragma unroll
-    for (int v = 0; v < 8; v += 2)
-        o[v] = pk_fma(splat(cosv(v, 3)), s3, pk_fma(splat(cosv(v, 2)), s2, pk_fma(splat(cosv(v, 1)), s1, splat(cosv(v, 0)) * s0)));
+__device__ __forceinline__ void dct8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7,
+                                     float (&o)[8]) {
+    const float s0 = a0 + a7, s1 = a1 + a6, s2 = a2 + a5, s3 = a3 + a4;
+    const float d0 = a0 - a7, d1 = a1 - a6, d2 = a2 - a5, d3 = a3 - a4;
+    const float ss0 = s0 + s3, ss1 = s1 + s2, sd0 = s0 - s3, sd1 = s1 - s2;
+    o[0] = ss0 + ss1;                                   // cos(0,.) = 1
+    o[4] = cosv(4, 0) * (ss0 - ss1);                    // cos(4,i) = +c4, -c4, -c4, +c4
+    o[2] = fmaf(cosv(2, 1), sd1, cosv(2, 0) * sd0);     // cos(2,i) = c2, c6, -c6, -c2
+    o[6] = fmaf(cosv(6, 1), sd1, cosv(6, 0) * sd0);     // cos(6,i) = c6, -c2, c2, -c6
 #pragma unroll
     for (int v = 1; v < 8; v += 2)
-        o[v] = pk_fma(splat(cosv(v, 3)), d3, pk_fma(splat(cosv(v, 2)), d2, pk_fma(splat(cosv(v, 1)), d1, splat(cosv(v, 0)) * d0)));
+        o[v] = fmaf(cosv(v, 3), d3, fmaf(cosv(v, 2), d2, fmaf(cosv(v, 1), d1, cosv(v, 0) * d0)));
 }
 
 template <bool CHROMA>
 __device__ __forceinline__ void transform_real(const uint32_t (&px)[16], uint32_t *slot) {
-    // row pass on pairs of rows: t[p][v] = (tmp[2p][v], tmp[2p+1][v])
-    f2 t[4][8];
+    float t[8][8];  // t[x][v] = sum_y e[x][y] cos(v,y); the level shift is applied to the DC sum below
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-        f2 e[8];
+    for (int x = 0; x < 8; x++) {
+        float e[8];
 #pragma unroll
-        for (int y = 0; y < 8; y++) {
-            e[y].x = (float)((px[4 * p + (y >> 2)] >> (8 * (y & 3))) & 0xffu);
-            e[y].y = (float)((px[4 * p + 2 + (y >> 2)] >> (8 * (y & 3))) & 0xffu);
-        }
-        dct8_pairs(e, t[p]);
+        for (int y = 0; y < 8; y++) e[y] = (float)((px[2 * x + (y >> 2)] >> (8 * (y & 3))) & 0xffu);
+        dct8(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], t[x]);
     }
-    // column pass on pairs of columns (v, v+1): a[x] = (tmp[x][v], tmp[x][v+1])
-    int res[64];
+    uint32_t w[32];
+    bool seen[32] = {};
 #pragma unroll
-    for (int v = 0; v < 8; v += 2) {
-        f2 a[8], o[8];
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            a[2 * p] = (f2){t[p][v].x, t[p][v + 1].x};
-            a[2 * p + 1] = (f2){t[p][v].y, t[p][v + 1].y};
-        }
-        dct8_pairs(a, o);
-        // level shift (src/jpeg/dct_quant.rs:63-65): subtracting 128 from every
-        // sample moves only the DC sum, by exactly 64*128
-        if (v == 0) o[0].x -= 8192.0f;
+    for (int v = 0; v < 8; v++) {
+        float o[8];
+        dct8(t[0][v], t[1][v], t[2][v], t[3][v], t[4][v], t[5][v], t[6][v], t[7][v], o);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int n0 = u * 8 + v, n1 = n0 + 1;
-            const f2 scale = {dct_scale(u, v), dct_scale(u, v + 1)};
-            const f2 q = {(float)quant<CHROMA>(n0), (float)quant<CHROMA>(n1)};
-            const f2 z = {rcp_rn(quant<CHROMA>(n0)), rcp_rn(quant<CHROMA>(n1))};
-            quantise_pair(o[u], scale, q, z, res[jpgtab::ZZ_OF_NATURAL.k[n0]], res[jpgtab::ZZ_OF_NATURAL.k[n1]]);
+            const int n = u * 8 + v;
+            int r;
+            if (n == 0) {
+                // level shift (src/jpeg/dct_quant.rs:63-65): subtracting 128 from every
+                // sample moves only the DC sum, by exactly 64*128; then the
+                // reference's ((0.25*au*av*sum)/q) as i16 (src/jpeg/dct_quant.rs:227-230)
+                const float s = dct_scale(0, 0) * (o[0] - 8192.0f);
+                r = (int)div_const(s, (float)quant<CHROMA>(0), rcp_rn(quant<CHROMA>(0)));
+            } else {
+                // scale and quantiser folded into one factor
+                r = (int)(o[u] * (dct_scale(u, v) / (float)quant<CHROMA>(n)));
+            }
+            const int k = jpgtab::ZZ_OF_NATURAL.k[n];
+            put16_rt(w, k, r, !seen[k >> 1]);
+            seen[k >> 1] = true;
         }
     }
-    store_zigzag(res, slot);
+    store_packed(w, slot);
 }
 
 // --- the reference's own summation order, bit-exact -------------------------
@@ -279,8 +295,8 @@ __device__ __forceinline__ void rgb_to_ycbcr(float r, float g, float b, uint32_t
     fy = fy + 0.114f * b;
     float fb = 128.0f - 0.168736f * r;
     fb = fb - 0.331264f * g;
-    fb = fb + 0.5f * b;
-    float fr = 128.0f + 0.5f * r;
+    fb = fmaf(0.5f, b, fb);        // 0.5*b is exact, so one rounding either way
+    float fr = fmaf(0.5f, r, 128.0f);  // exact: k/2 + 128 is representable
     fr = fr - 0.418688f * g;
     fr = fr - 0.081312f * b;
     y = (uint32_t)min(max((int)fy, 0), 255);
@@ -295,8 +311,8 @@ __device__ __forceinline__ void rgb_to_ycbcr2(f2 r, f2 g, f2 b, f2 &y, f2 &cb, f
     y = y + 0.114f * b;
     cb = 128.0f - 0.168736f * r;
     cb = cb - 0.331264f * g;
-    cb = cb + 0.5f * b;
-    cr = 128.0f + 0.5f * r;
+    cb = __builtin_elementwise_fma((f2){0.5f, 0.5f}, b, cb);                  // 0.5*b is exact
+    cr = __builtin_elementwise_fma((f2){0.5f, 0.5f}, r, (f2){128.0f, 128.0f});  // exact
     cr = cr - 0.418688f * g;
     cr = cr - 0.081312f * b;
 }

@@ -87,4 +87,5 @@ def test_real_dct_tolerance(J, oracle, ratio):
             assert d.max() <= 1
             total += d.size
             bad += int((d != 0).sum())
+    print("real-dct mismatches: %d of %d (%.5f %%)" % (bad, total, 100.0 * bad / total))
     assert bad <= 1e-4 * total, (bad, total)
