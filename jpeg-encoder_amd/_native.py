@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjpeg_hip.so")
+# JPEG_HIP_LIB selects another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("JPEG_HIP_LIB") or os.path.join(_HERE, "libjpeg_hip.so")
 
 DCT_REAL, DCT_BIN, DCT_REAL_STRICT = 0, 1, 2
 

@@ -47,19 +47,12 @@ struct TileCfg {
 // 4 pixels of one row: 12 bytes B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3 -> packed Y, Cb, Cr bytes
 __device__ __forceinline__ void convert4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t &y4, uint32_t (&cb)[4],
                                          uint32_t (&cr)[4]) {
-    const f2 r01 = {(float)((d0 >> 16) & 0xff), (float)((d1 >> 8) & 0xff)};
-    const f2 g01 = {(float)((d0 >> 8) & 0xff), (float)(d1 & 0xff)};
-    const f2 b01 = {(float)(d0 & 0xff), (float)(d0 >> 24)};
-    const f2 r23 = {(float)(d2 & 0xff), (float)(d2 >> 24)};
-    const f2 g23 = {(float)(d1 >> 24), (float)((d2 >> 16) & 0xff)};
-    const f2 b23 = {(float)((d1 >> 16) & 0xff), (float)((d2 >> 8) & 0xff)};
-    f2 y01, cb01, cr01, y23, cb23, cr23;
-    rgb_to_ycbcr2(r01, g01, b01, y01, cb01, cr01);
-    rgb_to_ycbcr2(r23, g23, b23, y23, cb23, cr23);
-    // `as u8`: truncation; the values are within [0, 256) by construction
-    y4 = (uint32_t)y01.x | ((uint32_t)y01.y << 8) | ((uint32_t)y23.x << 16) | ((uint32_t)y23.y << 24);
-    cb[0] = (uint32_t)cb01.x; cb[1] = (uint32_t)cb01.y; cb[2] = (uint32_t)cb23.x; cb[3] = (uint32_t)cb23.y;
-    cr[0] = (uint32_t)cr01.x; cr[1] = (uint32_t)cr01.y; cr[2] = (uint32_t)cr23.x; cr[3] = (uint32_t)cr23.y;
+    uint32_t y[4];
+    rgb_to_ycbcr((float)((d0 >> 16) & 0xff), (float)((d0 >> 8) & 0xff), (float)(d0 & 0xff), y[0], cb[0], cr[0]);
+    rgb_to_ycbcr((float)((d1 >> 8) & 0xff), (float)(d1 & 0xff), (float)(d0 >> 24), y[1], cb[1], cr[1]);
+    rgb_to_ycbcr((float)(d2 & 0xff), (float)(d1 >> 24), (float)((d1 >> 16) & 0xff), y[2], cb[2], cr[2]);
+    rgb_to_ycbcr((float)(d2 >> 24), (float)((d2 >> 16) & 0xff), (float)((d2 >> 8) & 0xff), y[3], cb[3], cr[3]);
+    y4 = y[0] | (y[1] << 8) | (y[2] << 16) | (y[3] << 24);
 }
 
 template <int HS, int VS>

@@ -299,9 +299,10 @@ __device__ __forceinline__ void rgb_to_ycbcr(float r, float g, float b, uint32_t
     float fr = fmaf(0.5f, r, 128.0f);  // exact: k/2 + 128 is representable
     fr = fr - 0.418688f * g;
     fr = fr - 0.081312f * b;
-    y = (uint32_t)min(max((int)fy, 0), 255);
-    cb = (uint32_t)min(max((int)fb, 0), 255);
-    cr = (uint32_t)min(max((int)fr, 0), 255);
+    // `as u8`: truncation; the three values lie in [0, 256) for every input, so nothing saturates
+    y = (uint32_t)fy;
+    cb = (uint32_t)fb;
+    cr = (uint32_t)fr;
 }
 
 
