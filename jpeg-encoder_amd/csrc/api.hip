@@ -30,12 +30,11 @@ struct jpg_ctx {
     uint8_t *d_down[2] = {nullptr, nullptr}; size_t down_cap = 0;              // Wc x Hc each
     int16_t *d_coef = nullptr; size_t coef_cap = 0;                            // in blocks
     int16_t *d_tmp16 = nullptr; size_t tmp16_cap = 0;
-    int16_t *d_pred = nullptr;   // [0..2] predictors in, [4..6] last DCs out
+    int16_t *d_dc = nullptr;     // last DCs out (3 values)
     EntropyBufs eb{};
     size_t ent_cap = 0;          // in blocks
-    uint64_t *h_totals = nullptr;  // pinned: [0] bits [1] stuffed bytes
-    int *h_err = nullptr;          // pinned
-    uint8_t *h_tail = nullptr;     // pinned
+    DevStatus *h_status = nullptr;  // pinned copy of eb.status
+    int16_t *h_dc = nullptr;        // pinned
     uint64_t nbits = 0;
     size_t scan_len = 0;
 };
@@ -120,13 +119,10 @@ extern "C" int jpg_create(jpg_ctx **out, int device, int dct_algo, int ra, int r
     c->device = device; c->algo = dct_algo; c->h = h; c->v = v;
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipHostMalloc((void **)&c->h_totals, 4 * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess &&
-              hipHostMalloc((void **)&c->h_err, sizeof(int), hipHostMallocDefault) == hipSuccess &&
-              hipHostMalloc((void **)&c->h_tail, 16, hipHostMallocDefault) == hipSuccess &&
-              hipMalloc((void **)&c->d_pred, 8 * sizeof(int16_t)) == hipSuccess &&
-              hipMalloc((void **)&c->eb.totals, 4 * sizeof(uint64_t)) == hipSuccess &&
-              hipMalloc((void **)&c->eb.error, sizeof(int)) == hipSuccess &&
-              hipMalloc((void **)&c->eb.tail, 16) == hipSuccess;
+              hipHostMalloc((void **)&c->h_status, sizeof(DevStatus), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_dc, 4 * sizeof(int16_t), hipHostMallocDefault) == hipSuccess &&
+              hipMalloc((void **)&c->d_dc, 4 * sizeof(int16_t)) == hipSuccess &&
+              hipMalloc((void **)&c->eb.status, sizeof(DevStatus)) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         jpg_destroy(c);
@@ -141,13 +137,12 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_src_own, c->d_plane[0], c->d_plane[1], c->d_plane[2], c->d_down[0], c->d_down[1], c->d_coef,
-                   c->d_tmp16, c->d_pred, c->eb.chunk_len, c->eb.chunk_off, c->eb.group_len, c->eb.group_base,
-                   c->eb.totals, c->eb.error, c->eb.bits, c->eb.seg_cnt, c->eb.seg_off, c->eb.scan, c->eb.tail};
+                   c->d_tmp16, c->d_dc, c->eb.blk_bits, c->eb.chunk_len, c->eb.chunk_base, c->eb.status,
+                   c->eb.bits, c->eb.seg_cnt, c->eb.seg_off, c->eb.scan};
     for (void *p : dev)
         if (p) (void)hipFree(p);
-    if (c->h_totals) (void)hipHostFree(c->h_totals);
-    if (c->h_err) (void)hipHostFree(c->h_err);
-    if (c->h_tail) (void)hipHostFree(c->h_tail);
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->h_dc) (void)hipHostFree(c->h_dc);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -187,7 +182,6 @@ static int ensure_entropy(jpg_ctx *c) {
     const size_t nblk = (size_t)c->g.nblocks;
     if (nblk <= c->ent_cap) return JPG_OK;
     const size_t nchunks = (nblk + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
-    const size_t ngroups = (nchunks + GROUP_CHUNKS - 1) / GROUP_CHUNKS;
     // worst case: every block at its maximum coded size
     size_t bits_bytes = (nblk * MAX_BLOCK_BITS + 7) / 8 + 64;
     bits_bytes = (bits_bytes + 15) / 16 * 16;
@@ -203,10 +197,9 @@ static int ensure_entropy(jpg_ctx *c) {
         }
         return grow(c, p, cc, n);
     };
+    if ((e = re(c->eb.blk_bits, nblk))) return e;
     if ((e = re(c->eb.chunk_len, nchunks))) return e;
-    if ((e = re(c->eb.chunk_off, nchunks))) return e;
-    if ((e = re(c->eb.group_len, ngroups))) return e;
-    if ((e = re(c->eb.group_base, ngroups))) return e;
+    if ((e = re(c->eb.chunk_base, nchunks))) return e;
     if ((e = re(c->eb.bits, bits_bytes / 4))) return e;
     if ((e = re(c->eb.seg_cnt, nseg))) return e;
     if ((e = re(c->eb.seg_off, nseg))) return e;
@@ -299,22 +292,13 @@ extern "C" int jpg_dct_quant(jpg_ctx *c) {
 
 static int queue_entropy(jpg_ctx *c, const int16_t pred[3]) {
     if (int e = ensure_entropy(c)) return e;
-    if (pred) {
-        // small, synchronous with respect to the host buffer
-        int16_t *hp = reinterpret_cast<int16_t *>(c->h_tail) + 4;
-        hp[0] = pred[0]; hp[1] = pred[1]; hp[2] = pred[2];
-        HIP_TRY(c, hipMemcpyAsync(c->d_pred, hp, 3 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
-    } else {
-        HIP_TRY(c, hipMemsetAsync(c->d_pred, 0, 3 * sizeof(int16_t), c->stream));
-    }
-    HIP_TRY(c, launch_entropy(c->g, c->d_coef, c->d_pred, c->eb, c->stream));
+    static const int16_t zero[3] = {0, 0, 0};   // src/jpeg/entropy_coding.rs:38-40
+    HIP_TRY(c, launch_entropy(c->g, c->d_coef, pred ? pred : zero, c->eb, c->stream));
     return JPG_OK;
 }
 
-static int fetch_totals(jpg_ctx *c) {
-    HIP_TRY(c, hipMemcpyAsync(c->h_totals, c->eb.totals, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_err, c->eb.error, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_tail, c->eb.tail, 1, hipMemcpyDeviceToHost, c->stream));
+static int fetch_status(jpg_ctx *c) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_status, c->eb.status, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
     return JPG_OK;
 }
 
@@ -323,10 +307,10 @@ static int entropy_common(jpg_ctx *c, const int16_t *pred, uint64_t *nbits) {
     if (c->stage < ST_COEF) return JPG_ERR_STATE;
     if (int e = use_device(c)) return e;
     if (int e = queue_entropy(c, pred)) return e;
-    if (int e = fetch_totals(c)) return e;
+    if (int e = fetch_status(c)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (*c->h_err) return *c->h_err;
-    c->nbits = c->h_totals[0];
+    if (c->h_status->error) return c->h_status->error;
+    c->nbits = c->h_status->nbits;
     if (nbits) *nbits = c->nbits;
     c->stage = ST_BITS;
     return JPG_OK;
@@ -342,11 +326,10 @@ extern "C" int jpg_last_dc(jpg_ctx *c, int16_t dc[3]) {
     if (!c || !dc) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_COEF) return JPG_ERR_STATE;
     if (int e = use_device(c)) return e;
-    HIP_TRY(c, launch_last_dc(c->g, c->d_coef, c->d_pred + 4, c->stream));
-    int16_t *hp = reinterpret_cast<int16_t *>(c->h_tail) + 4;
-    HIP_TRY(c, hipMemcpyAsync(hp, c->d_pred + 4, 3 * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, launch_last_dc(c->g, c->d_coef, c->d_dc, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_dc, c->d_dc, 3 * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    dc[0] = hp[0]; dc[1] = hp[1]; dc[2] = hp[2];
+    dc[0] = c->h_dc[0]; dc[1] = c->h_dc[1]; dc[2] = c->h_dc[2];
     return JPG_OK;
 }
 
@@ -355,11 +338,11 @@ extern "C" int jpg_stitch(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, in
     if (c->stage < ST_BITS) return JPG_ERR_STATE;
     if (int e = use_device(c)) return e;
     HIP_TRY(c, launch_stuff(c->eb, bit_offset, head_bits, is_last, c->stream));
-    if (int e = fetch_totals(c)) return e;
+    if (int e = fetch_status(c)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->scan_len = (size_t)c->h_totals[1];
+    c->scan_len = (size_t)c->h_status->scan_bytes;
     if (len) *len = c->scan_len;
-    if (tail) *tail = c->h_tail[0];
+    if (tail) *tail = (uint8_t)c->h_status->tail;
     c->stage = ST_SCAN;
     return JPG_OK;
 }
@@ -383,7 +366,7 @@ extern "C" int jpg_encode_device_async(jpg_ctx *c, const uint8_t *dev_pixels, in
     if (int e = jpg_front_device(c, dev_pixels, W, H, stride, bottom_up)) return e;
     if (int e = queue_entropy(c, nullptr)) return e;
     HIP_TRY(c, launch_stuff(c->eb, 0, 0, 1, c->stream));
-    if (int e = fetch_totals(c)) return e;
+    if (int e = fetch_status(c)) return e;
     c->pending = true;
     return JPG_OK;
 }
@@ -394,9 +377,9 @@ extern "C" int jpg_finish(jpg_ctx *c, uint64_t *nbits, size_t *stuffed_len) {
     if (int e = use_device(c)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->pending = false;
-    if (*c->h_err) return *c->h_err;
-    c->nbits = c->h_totals[0];
-    c->scan_len = (size_t)c->h_totals[1];
+    if (c->h_status->error) return c->h_status->error;
+    c->nbits = c->h_status->nbits;
+    c->scan_len = (size_t)c->h_status->scan_bytes;
     if (nbits) *nbits = c->nbits;
     if (stuffed_len) *stuffed_len = c->scan_len;
     c->stage = ST_SCAN;
@@ -415,7 +398,7 @@ extern "C" int jpg_encode_scan(jpg_ctx *c, const uint8_t *pixels, int32_t W, int
     c->stage = ST_COEF;
     if (int e = queue_entropy(c, nullptr)) return e;
     HIP_TRY(c, launch_stuff(c->eb, 0, 0, 1, c->stream));
-    if (int e = fetch_totals(c)) return e;
+    if (int e = fetch_status(c)) return e;
     c->pending = true;
     if (int e = jpg_finish(c, nullptr, nullptr)) return e;
     void *host = nullptr;

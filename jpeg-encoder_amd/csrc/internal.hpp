@@ -29,23 +29,27 @@ struct Geom {
 
 enum { ALGO_REAL = 0, ALGO_BIN = 1, ALGO_REAL_STRICT = 2 };
 
-// Entropy-stage geometry: one wavefront codes a "chunk" of 8 consecutive
-// blocks; a workgroup of 4 waves codes a "group" of 32 chunks.
-constexpr int CHUNK_BLOCKS = 8;
-constexpr int GROUP_CHUNKS = 32;
-constexpr int GROUP_BLOCKS = CHUNK_BLOCKS * GROUP_CHUNKS;
+// Entropy-stage geometry: one thread codes one block; one wavefront codes a
+// "chunk" of 64 consecutive blocks, whose bits it assembles in LDS.
+constexpr int CHUNK_BLOCKS = 64;
 // worst-case coded size of one block: DC 9+11 bits, 63 AC x (16+10) bits
 constexpr int MAX_BLOCK_BITS = 20 + 63 * 26;
 // byte-stuffing works on segments of this many unstuffed bytes
 constexpr int STUFF_SEG = 4096;
 
+// results a host needs after an encode, fetched with one copy
+struct DevStatus {
+    uint64_t nbits;       // bits of the unstuffed stream
+    uint64_t scan_bytes;  // bytes of the stuffed stream
+    int32_t error;        // sticky jpg_status raised by a kernel (0 = none)
+    uint32_t tail;        // bits of the dropped partial byte (stripes)
+};
+
 struct EntropyBufs {
+    uint16_t *blk_bits;    // [nblocks] coded bits of each block
     uint32_t *chunk_len;   // [nchunks] bits of each chunk
-    uint32_t *chunk_off;   // [nchunks] bit offset of the chunk inside its group
-    uint32_t *group_len;   // [ngroups]
-    uint64_t *group_base;  // [ngroups] bit offset of the group in the stream
-    uint64_t *totals;      // [0] total bits, [1] stuffed byte count, [2] unstuffed bytes consumed by stitch
-    int *error;            // sticky jpg_status raised by a kernel
+    uint64_t *chunk_base;  // [nchunks] bit offset of the chunk in the stream
+    DevStatus *status;
     uint32_t *bits;        // unstuffed MSB-first stream, as 32-bit words in memory byte order
     size_t bits_cap;       // bytes
     uint32_t *seg_cnt;     // [nseg_cap] 0xFF bytes per stuffing segment
@@ -53,7 +57,6 @@ struct EntropyBufs {
     uint8_t *scan;         // stuffed stream
     size_t scan_cap;
     size_t nseg_cap;
-    uint8_t *tail;         // [1] bits of the dropped partial byte (stripes)
 };
 
 hipError_t launch_front(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s);
@@ -65,8 +68,8 @@ hipError_t launch_dct_planes(const Geom &g, int algo, const uint8_t *y, const ui
 hipError_t launch_unscan(const Geom &g, const int16_t *coef, int comp, int16_t *plane, hipStream_t s);
 hipError_t launch_last_dc(const Geom &g, const int16_t *coef, int16_t *dc3, hipStream_t s);
 
-// pred: device pointer to 3 int16 DC predictors (Y, Cb, Cr) for the first blocks
-hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t *pred, const EntropyBufs &b,
+// pred: the 3 DC predictors (Y, Cb, Cr) the first blocks start from
+hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred[3], const EntropyBufs &b,
                           hipStream_t s);
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s);
 
