@@ -33,6 +33,7 @@ struct jpg_ctx {
     int16_t *d_dc = nullptr;     // last DCs out (3 values)
     EntropyBufs eb{};
     size_t ent_cap = 0;          // in blocks
+    size_t hw_cap = 0;           // hand-off words per array
     DevStatus *h_status = nullptr;  // pinned copy of eb.status
     int16_t *h_dc = nullptr;        // pinned
     uint64_t nbits = 0;
@@ -122,7 +123,9 @@ extern "C" int jpg_create(jpg_ctx **out, int device, int dct_algo, int ra, int r
               hipHostMalloc((void **)&c->h_status, sizeof(DevStatus), hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void **)&c->h_dc, 4 * sizeof(int16_t), hipHostMallocDefault) == hipSuccess &&
               hipMalloc((void **)&c->d_dc, 4 * sizeof(int16_t)) == hipSuccess &&
-              hipMalloc((void **)&c->eb.status, sizeof(DevStatus)) == hipSuccess;
+              hipMalloc((void **)&c->eb.status, sizeof(DevStatus)) == hipSuccess &&
+              hipMalloc((void **)&c->eb.ticket, sizeof(uint32_t)) == hipSuccess &&
+              hipMemset(c->eb.ticket, 0, sizeof(uint32_t)) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         jpg_destroy(c);
@@ -137,7 +140,7 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_src_own, c->d_plane[0], c->d_plane[1], c->d_plane[2], c->d_down[0], c->d_down[1], c->d_coef,
-                   c->d_tmp16, c->d_dc, c->eb.blk_bits, c->eb.chunk_len, c->eb.chunk_base, c->eb.status,
+                   c->d_tmp16, c->d_dc, c->eb.agg, c->eb.grp, c->eb.hyp, c->eb.tail, c->eb.ticket, c->eb.status,
                    c->eb.bits, c->eb.seg_cnt, c->eb.seg_off, c->eb.scan};
     for (void *p : dev)
         if (p) (void)hipFree(p);
@@ -197,9 +200,12 @@ static int ensure_entropy(jpg_ctx *c) {
         }
         return grow(c, p, cc, n);
     };
-    if ((e = re(c->eb.blk_bits, nblk))) return e;
-    if ((e = re(c->eb.chunk_len, nchunks))) return e;
-    if ((e = re(c->eb.chunk_base, nchunks))) return e;
+    if ((e = re(c->eb.agg, nchunks))) return e;
+    if ((e = re(c->eb.grp, nchunks / 64 + 1))) return e;
+    if ((e = re(c->eb.hyp, nchunks / 4096 + 1))) return e;
+    if ((e = re(c->eb.tail, nchunks))) return e;
+    c->hw_cap = nchunks;
+    c->eb.epoch = 0;   // forces the hand-off words to be cleared before first use
     if ((e = re(c->eb.bits, bits_bytes / 4))) return e;
     if ((e = re(c->eb.seg_cnt, nseg))) return e;
     if ((e = re(c->eb.seg_off, nseg))) return e;
@@ -292,6 +298,17 @@ extern "C" int jpg_dct_quant(jpg_ctx *c) {
 
 static int queue_entropy(jpg_ctx *c, const int16_t pred[3]) {
     if (int e = ensure_entropy(c)) return e;
+    // a new generation of hand-off words per launch; clear them when the 14-bit counter wraps
+    if (c->eb.epoch == 0 || c->eb.epoch >= 16383) {
+        HIP_TRY(c, hipMemsetAsync(c->eb.agg, 0, c->hw_cap * sizeof(uint64_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->eb.grp, 0, (c->hw_cap / 64 + 1) * sizeof(uint64_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->eb.hyp, 0, (c->hw_cap / 4096 + 1) * sizeof(uint64_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->eb.tail, 0, c->hw_cap * sizeof(uint64_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->eb.ticket, 0, sizeof(uint32_t), c->stream));
+        c->eb.epoch = 0;
+    }
+    c->eb.epoch++;
+    c->eb.host_status = c->h_status;
     static const int16_t zero[3] = {0, 0, 0};   // src/jpeg/entropy_coding.rs:38-40
     HIP_TRY(c, launch_entropy(c->g, c->d_coef, pred ? pred : zero, c->eb, c->stream));
     return JPG_OK;

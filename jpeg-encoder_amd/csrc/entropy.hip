@@ -3,20 +3,23 @@
 // (src/jpeg/entropy_coding.rs:201-227), MSB-first bit packing
 // (src/utils/bitvec_utils.rs:3-8) and 0xFF byte stuffing
 // (src/jpeg/file.rs:92-103).  The reference does this serially; here the
-// variable-length output is placed by prefix sums:
+// variable-length output is placed by prefix sums.
 //
-//   k_entropy<false>  one thread per block: coded length of the block; one
-//                     wavefront per chunk of 64 blocks: length of the chunk
-//   k_scan_chunks     exclusive scan of the chunk lengths (one workgroup); also
-//                     clears the first and last word of every chunk, which
-//                     neighbouring chunks share and therefore OR into
-//   k_entropy<true>   codes the blocks again, assembles each chunk's bits in
-//                     LDS at their final alignment and writes them out
-//   k_ff_count / k_ff_scan / k_ff_scatter   the same three steps for stuffing
+// k_entropy: one thread codes one block, one wavefront a chunk of 64
+// consecutive blocks.  A thread walks only the non-zero coefficients of its
+// block (a 64-bit mask built while the block is read from LDS), so the work
+// follows the number of symbols, not the number of coefficients.  The wave
+//   1. measures its blocks, scans the lengths, announces the chunk's length,
+//   2. codes the blocks into LDS (bit 0 = first bit of the chunk),
+//   3. learns the chunk's bit offset in the stream from the lengths announced
+//      by the chunks before it (three levels of sums, so nobody waits on a chain),
+//   4. writes the bits to global memory shifted to that offset, as whole
+//      words: the word a chunk shares with its predecessor is written by the
+//      later chunk, which gets the predecessor's last 32 bits handed over.
+// A wave only ever waits for chunks with a lower number, which belong to
+// workgroups dispatched before its own.
 //
-// A thread walks only the non-zero coefficients of its block (a 64-bit mask
-// built while the block is read from LDS), so the work follows the number of
-// symbols, not the number of coefficients.
+// k_ff_count / k_ff_scan / k_ff_scatter then insert 0x00 after every 0xFF.
 #include "../../include/jpeg_hip.h"
 #include "internal.hpp"
 #include "tables.h"
@@ -25,8 +28,9 @@ namespace jpg {
 
 __device__ const jpgtab::HuffLut HUFF_DEV{};
 constexpr int LUT_WORDS = 2 * jpgtab::HUFF_LUT_STRIDE;
-constexpr int ENT_THREADS = 256;
+constexpr int ENT_THREADS = 128;
 constexpr int ENT_WAVES = ENT_THREADS / 64;
+constexpr uint32_t SPIN_LIMIT = 1u << 22;       // polls before a wave gives up waiting (never hang the GPU)
 constexpr int SLOT_BYTES = 144;                 // 128-byte block + 16: conflict-free 16-byte LDS access
 constexpr int OUT_WORDS = 1024;                 // LDS words a chunk's bits may take on the fast path (4 KiB)
 
@@ -43,15 +47,28 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 
 struct EntArgs {
     const int16_t *coef;
-    long long nblocks;
+    long long nblocks, nchunks;
     int nb, hv;
     int16_t pred[3];
-    uint16_t *blk_bits;
-    uint32_t *chunk_len;
-    const uint64_t *chunk_base;
+    uint32_t epoch;
+    uint64_t *agg, *grp, *hyp, *tail;
+    uint32_t *ticket;
     uint32_t *bits;
     DevStatus *status;
 };
+
+// hand-off word: {epoch:14 | valid:1 | value:49}
+__device__ __forceinline__ uint64_t hw_pack(uint32_t epoch, uint64_t value) {
+    return ((uint64_t)((epoch << 1) | 1u) << 49) | value;
+}
+__device__ __forceinline__ bool hw_valid(uint64_t w, uint32_t epoch) { return (w >> 49) == (uint64_t)((epoch << 1) | 1u); }
+__device__ __forceinline__ uint64_t hw_value(uint64_t w) { return w & ((1ull << 49) - 1); }
+__device__ __forceinline__ void hw_store(uint64_t *p, uint64_t w) {
+    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t hw_load(const uint64_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // MSB-first bit writer into a zeroed LDS word array (words may be shared with
 // neighbouring blocks, hence OR)
@@ -74,29 +91,6 @@ struct BitWriter {
     }
     __device__ __forceinline__ void finish() {
         if (n) atomicOr(&out[wpos], (uint32_t)(acc << (32 - n)));
-    }
-};
-
-// same interface, every word OR-ed straight into global memory (chunks whose
-// bits do not fit the LDS window)
-struct BitWriterGlobal {
-    uint32_t *out;
-    uint64_t wpos;
-    uint64_t acc;
-    uint32_t n;
-    __device__ __forceinline__ void init(uint32_t *o, uint64_t bitpos) {
-        out = o; wpos = bitpos >> 5; n = (uint32_t)(bitpos & 31); acc = 0;
-    }
-    __device__ __forceinline__ void put(uint32_t value, uint32_t len) {
-        acc = (acc << len) | value;
-        n += len;
-        if (n >= 32) {
-            n -= 32;
-            atomicOr(&out[wpos++], __builtin_bswap32((uint32_t)(acc >> n)));
-        }
-    }
-    __device__ __forceinline__ void finish() {
-        if (n) atomicOr(&out[wpos], __builtin_bswap32((uint32_t)(acc << (32 - n))));
     }
 };
 
@@ -176,19 +170,70 @@ __device__ __forceinline__ void nonzero_mask(const uint4 (&q)[8], uint32_t &mlo,
     mhi = m[1];
 }
 
-template <bool PACK>
+// poll a hand-off word until it carries this launch's epoch
+__device__ __forceinline__ uint64_t hw_wait(const uint64_t *p, bool need, uint32_t epoch, bool &timeout) {
+    uint64_t w = 0;
+    bool ok = !need;
+    for (uint32_t spin = 0;; spin++) {
+        if (!ok) {
+            w = hw_load(p);
+            ok = hw_valid(w, epoch);
+        }
+        if (__ballot(!ok) == 0) break;
+        if (spin >= SPIN_LIMIT) { timeout = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return need && ok ? hw_value(w) : 0;
+}
+
+// Bit offset of chunk `chunk` in the stream = sum of the lengths of all chunks
+// before it, gathered from three levels of sums so that no wave waits on a chain:
+//   agg[c]  bits of chunk c            (published by c right after measuring)
+//   grp[g]  bits of chunks 64g..64g+63 (published by the last chunk of the group)
+//   hyp[h]  bits of groups 64h..64h+63 (published by the last chunk of the hyper-group)
+// offset(c) = sum hyp[< h] + sum grp[64h .. g-1] + sum agg[64g .. c-1].  The wave
+// that closes a group or hyper-group publishes its sum from the same partial sums.
+__device__ __forceinline__ uint64_t chunk_offset(const EntArgs &a, long long chunk, uint32_t total, int lane,
+                                                 bool &timeout) {
+    const long long g = chunk >> 6, h = g >> 6;
+    const bool closes_group = (chunk & 63) == 63 || chunk == a.nchunks - 1;
+    const bool closes_hyper = closes_group && ((g & 63) == 63 || chunk == a.nchunks - 1);
+    // each sum is published as soon as it is known, before waiting for anything else,
+    // so the publications never form a chain
+    const long long ia = (g << 6) + lane;
+    const uint32_t sum_a = __shfl(wave_incl_scan((uint32_t)hw_wait(&a.agg[ia], ia < chunk, a.epoch, timeout)), 63);
+    const uint64_t gv = (uint64_t)sum_a + total;
+    if (closes_group && lane == 0) hw_store(&a.grp[g], hw_pack(a.epoch, gv));
+    const long long ig = (h << 6) + lane;
+    const uint32_t sum_g = __shfl(wave_incl_scan((uint32_t)hw_wait(&a.grp[ig], ig < g, a.epoch, timeout)), 63);
+    if (closes_hyper && lane == 0) hw_store(&a.hyp[h], hw_pack(a.epoch, (uint64_t)sum_g + gv));
+    uint64_t sh = 0;
+    for (long long j0 = 0; j0 < h; j0 += 64) sh += hw_wait(&a.hyp[j0 + lane], j0 + lane < h, a.epoch, timeout);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)sh, d), hi = __shfl_xor((uint32_t)(sh >> 32), d);
+        sh += ((uint64_t)hi << 32) | lo;
+    }
+    return sh + sum_g + sum_a;
+}
+
 __global__ __launch_bounds__(ENT_THREADS) void k_entropy(EntArgs a) {
     __shared__ uint32_t sLut[LUT_WORDS];
     __shared__ __attribute__((aligned(16))) uint8_t sCoef[ENT_WAVES][CHUNK_BLOCKS * SLOT_BYTES];
-    __shared__ uint32_t sOut[PACK ? ENT_WAVES : 1][PACK ? OUT_WORDS + 2 : 1];
+    __shared__ uint32_t sOut[ENT_WAVES][OUT_WORDS + 2];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < LUT_WORDS; i += ENT_THREADS) sLut[i] = (&HUFF_DEV.e[0][0])[i];
-    __syncthreads();
 
+    __syncthreads();
+    // A wave waits only for chunks with a lower number (see chunk_offset and the tail
+    // hand-off), i.e. for workgroups with a lower blockIdx.  Workgroups are dispatched in
+    // blockIdx order, so those are already running or finished; every wait is bounded all
+    // the same and ends in JPG_ERR_HIP rather than a hang.
     const long long chunk = (long long)blockIdx.x * ENT_WAVES + wave;
+    if (chunk >= a.nchunks) return;                              // wave-uniform; no workgroup barrier follows
+    {
     const long long first = chunk * CHUNK_BLOCKS;
-    if (first >= a.nblocks) return;                               // wave-uniform; no barrier follows
     const int nvalid = (int)min((long long)CHUNK_BLOCKS, a.nblocks - first);
 
     // stage the chunk's coefficients: coalesced 16-byte loads, one padded slot per block
@@ -223,79 +268,125 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy(EntArgs a) {
     }
     const uint32_t *lut = sLut + chroma * jpgtab::HUFF_LUT_STRIDE;
 
-    if (!PACK) {
-        NullWriter w;
-        const uint32_t bits = valid ? code_block(slot, mlo, mhi, dc_diff, lut, &a.status->error, w) : 0u;
-        if (valid) a.blk_bits[blk] = (uint16_t)bits;
-        const uint32_t sc = wave_incl_scan(bits);
-        if (lane == 63) a.chunk_len[chunk] = sc;
-    } else {
-        const uint32_t len = valid ? (uint32_t)a.blk_bits[blk] : 0u;
-        const uint32_t sc = wave_incl_scan(len);
-        const uint32_t total = __shfl(sc, 63);
-        const uint64_t O = a.chunk_base[chunk];
-        const uint32_t shift = (uint32_t)(O & 31);
-        const uint64_t W0 = O >> 5;
-        const uint32_t nwords = (shift + total + 31) >> 5;
-        if (nwords <= OUT_WORDS) {
-            // fast path: assemble in LDS at the final bit alignment, then write whole words
-            for (uint32_t i = lane; i < nwords; i += 64) sOut[wave][i] = 0;
-            __builtin_amdgcn_wave_barrier();
-            if (valid) {
-                BitWriter w;
-                w.init(sOut[wave], shift + sc - len);
-                code_block(slot, mlo, mhi, dc_diff, lut, &a.status->error, w);
-            }
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = lane; i < nwords; i += 64) {
-                const uint32_t v = __builtin_bswap32(sOut[wave][i]);
-                if (i == 0 || i == nwords - 1) atomicOr(&a.bits[W0 + i], v);   // shared with the neighbouring chunk
-                else a.bits[W0 + i] = v;
-            }
-        } else {
-            // dense chunk: clear the words this chunk owns alone, then OR every word in global memory
-            for (uint32_t i = 1 + lane; i + 1 < nwords; i += 64) a.bits[W0 + i] = 0;
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
-            if (valid) {
-                BitWriterGlobal w;
-                w.init(a.bits, O + sc - len);
-                code_block(slot, mlo, mhi, dc_diff, lut, &a.status->error, w);
-            }
+    // 1. lengths
+    NullWriter nw;
+    const uint32_t len = valid ? code_block(slot, mlo, mhi, dc_diff, lut, &a.status->error, nw) : 0u;
+    const uint32_t sc = wave_incl_scan(len);                      // bits up to and including this lane's block
+    const uint32_t total = __shfl(sc, 63);
+    if (lane == 0) hw_store(&a.agg[chunk], hw_pack(a.epoch, total));
+
+    // 2..4. code and write out; a chunk too long for the LDS window goes in several passes
+    uint32_t *out = sOut[wave];
+    constexpr uint32_t WINDOW = OUT_WORDS * 32;                   // bits per pass
+    uint64_t O = 0;                                               // bit offset of the chunk, known after the first pass
+    uint32_t prev_tail = 0;                                       // the 32 stream bits before the current pass
+    uint32_t done = 0;                                            // bits of the chunk already written out
+    bool timeout = false;
+    for (int pass = 0; done < total || pass == 0; pass++) {
+        // lanes whose block ends within the window starting at `done` (at least one: a block is < WINDOW bits)
+        const bool mine = valid && sc > done && sc - done <= WINDOW;
+        const uint32_t pass_bits = __shfl(mine ? sc - done : 0u, 63 - __clzll(__ballot(mine) | 1ull));
+        const uint32_t nw_local = (pass_bits + 31) >> 5;
+        for (uint32_t i = lane; i < nw_local + 1; i += 64) out[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (mine) {
+            BitWriter w;
+            w.init(out, sc - len - done);
+            code_block(slot, mlo, mhi, dc_diff, lut, &a.status->error, w);
         }
+        __builtin_amdgcn_wave_barrier();
+        const bool last_pass = done + pass_bits >= total;
+        // last 32 bits of the stream after this pass
+        uint32_t new_tail;
+        {
+            const uint32_t e = pass_bits;                         // > 0
+            const uint32_t wi = (e - 1) >> 5, r = e & 31;         // r = bits used in the last word (0 = full)
+            const uint32_t lastw = out[wi], beforew = wi ? out[wi - 1] : prev_tail;
+            new_tail = r ? __funnelshift_r(lastw, beforew, 32 - r) : lastw;
+            if (e < 32) new_tail = (prev_tail << e) | (out[0] >> (32 - e));
+        }
+        if (last_pass && lane == 0) hw_store(&a.tail[chunk], hw_pack(a.epoch, new_tail));
+        if (pass == 0) {
+            // 3. where does the chunk start?
+#if defined(JPG_ENT_NOWAIT) && (JPG_ENT_NOWAIT & 1)
+            O = (uint64_t)chunk * 4096;
+#else
+            O = chunk_offset(a, chunk, total, lane, timeout);
+#endif
+#if defined(JPG_ENT_NOWAIT) && (JPG_ENT_NOWAIT & 2)
+            if (false) {
+#else
+            if (chunk > 0) {
+#endif
+                uint64_t tw = 0;
+                for (uint32_t spin = 0; lane == 0; spin++) {
+                    tw = hw_load(&a.tail[chunk - 1]);
+                    if (hw_valid(tw, a.epoch)) break;
+                    if (spin >= SPIN_LIMIT) { timeout = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                prev_tail = __shfl((uint32_t)hw_value(tw), 0);
+            }
+            if (chunk == a.nchunks - 1 && lane == 0) a.status->nbits = O + total;
+            if (__ballot(timeout) && lane == 0) atomicMin(&a.status->error, (int)JPG_ERR_HIP);
+        }
+        // 4. write the pass at bit O + done: word i = stream bits, preceded by prev_tail
+        const uint64_t P = O + done;
+        const uint32_t shift = (uint32_t)(P & 31);
+        const uint64_t W0 = P >> 5;
+        const uint32_t end_bits = shift + pass_bits;
+        // whole words only, except at the very end of the stream
+        const uint32_t nout = (last_pass && chunk == a.nchunks - 1) ? (end_bits + 31) >> 5 : end_bits >> 5;
+        for (uint32_t i = lane; i < nout; i += 64) {
+            const uint32_t hi = i ? out[i - 1] : prev_tail;
+            const uint32_t lo = i < nw_local ? out[i] : 0u;
+            a.bits[W0 + i] = __builtin_bswap32(shift ? __funnelshift_r(lo, hi, shift) : lo);
+        }
+        __builtin_amdgcn_wave_barrier();
+        prev_tail = new_tail;
+        done += pass_bits;
+    }
     }
 }
 
-// One workgroup: exclusive scan of the chunk lengths into 64-bit bit offsets,
-// total into status->nbits, and zero of every chunk's first and last word.
-__global__ __launch_bounds__(1024) void k_scan_chunks(const uint32_t *__restrict__ len, long long n,
-                                                      uint64_t *__restrict__ base, DevStatus *__restrict__ status,
-                                                      uint32_t *__restrict__ bits) {
-    __shared__ uint64_t s[1024];
-    const int tid = threadIdx.x;
-    const long long per = (n + 1023) / 1024;
-    const long long lo = min(n, tid * per), hi = min(n, lo + per);
-    uint64_t sum = 0;
-    for (long long i = lo; i < hi; i++) sum += len[i];
-    s[tid] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const uint64_t t = tid >= d ? s[tid - d] : 0;
-        __syncthreads();
-        s[tid] += t;
-        __syncthreads();
-    }
-    uint64_t run = s[tid] - sum;
-    for (long long i = lo; i < hi; i++) {
-        const uint32_t L = len[i];
-        base[i] = run;
-        if (L) {
-            bits[run >> 5] = 0;
-            bits[(run + L - 1) >> 5] = 0;
+// Exclusive scan of n 32-bit values by one workgroup of 1024 threads:
+// emit(i, offset, value) is called once per entry, the total is returned.
+// Rounds of 1024 consecutive entries (coalesced), eight rounds of loads in
+// flight at a time; each round is a wave scan plus a 16-entry LDS scan.
+template <class Emit>
+__device__ __forceinline__ uint64_t block_scan_1024(const uint32_t *__restrict__ len, long long n, Emit emit) {
+    __shared__ uint32_t s[2][16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint64_t carry = 0;
+    constexpr int B = 8;
+    int buf = 0;
+    for (long long r0 = 0; r0 < n; r0 += 1024LL * B) {
+        uint32_t L[B];
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            const long long i = r0 + 1024LL * r + tid;
+            L[r] = i < n ? len[i] : 0u;
         }
-        run += L;
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            const long long i = r0 + 1024LL * r + tid;
+            if (r0 + 1024LL * r >= n) break;                     // uniform
+            const uint32_t sc = wave_incl_scan(L[r]);
+            if (lane == 63) s[buf][wave] = sc;
+            __syncthreads();
+            uint32_t before = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) {
+                const uint32_t t = s[buf][w];
+                before += w < wave ? t : 0u;
+                all += t;
+            }
+            buf ^= 1;                                            // next round writes the other copy: one barrier per round
+            if (i < n) emit(i, carry + before + (sc - L[r]), L[r]);
+            carry += all;
+        }
     }
-    if (tid == 1023) status->nbits = s[1023];
+    return carry;
 }
 
 // ---------------------------------------------------------------- stuffing
@@ -309,6 +400,7 @@ struct StuffArgs {
     uint32_t *seg_cnt;
     uint64_t *seg_off;
     uint8_t *out;
+    DevStatus *host_status;  // pinned host copy, filled by the last kernel (may be null)
 };
 
 __device__ __forceinline__ uint64_t shifted_bytes(const StuffArgs &a) {
@@ -365,29 +457,13 @@ __global__ __launch_bounds__(256) void k_ff_count(StuffArgs a) {
 }
 
 __global__ __launch_bounds__(1024) void k_ff_scan(StuffArgs a) {
-    __shared__ uint64_t s[1024];
-    const int tid = threadIdx.x;
     const uint64_t nbytes = shifted_bytes(a);
     const long long n = (long long)((nbytes + STUFF_SEG - 1) / STUFF_SEG);
-    const long long per = (n + 1023) / 1024;
-    const long long lo = min(n, tid * per), hi = min(n, lo + per);
-    uint64_t sum = 0;
-    for (long long i = lo; i < hi; i++) sum += a.seg_cnt[i];
-    s[tid] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const uint64_t t = tid >= d ? s[tid - d] : 0;
-        __syncthreads();
-        s[tid] += t;
-        __syncthreads();
-    }
-    uint64_t run = s[tid] - sum;
-    for (long long i = lo; i < hi; i++) {
-        a.seg_off[i] = (uint64_t)i * STUFF_SEG + run;
-        run += a.seg_cnt[i];
-    }
-    if (tid == 1023) a.status->scan_bytes = nbytes + s[1023];
-    if (tid == 0) {
+    const uint64_t total = block_scan_1024(a.seg_cnt, n, [&](long long i, uint64_t off, uint32_t) {
+        a.seg_off[i] = (uint64_t)i * STUFF_SEG + off;
+    });
+    if (threadIdx.x == 0) {
+        a.status->scan_bytes = nbytes + total;
         // bits of the partial byte a non-final stripe leaves to its successor
         const uint64_t tbits = a.status->nbits + a.shift;
         uint32_t tail = 0;
@@ -436,6 +512,7 @@ __global__ __launch_bounds__(256) void k_ff_scatter(StuffArgs a) {
         }
         __syncthreads();
     }
+    if (a.host_status && blockIdx.x == 0 && threadIdx.x == 0) *a.host_status = *a.status;
 }
 
 hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred[3], const EntropyBufs &b,
@@ -444,15 +521,14 @@ hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred
     const unsigned grid = (unsigned)((nchunks + ENT_WAVES - 1) / ENT_WAVES);
     hipError_t e = hipMemsetAsync(b.status, 0, sizeof(DevStatus), s);
     if (e != hipSuccess) return e;
-    EntArgs a{coef, g.nblocks, g.nb, g.h * g.v, {pred[0], pred[1], pred[2]}, b.blk_bits, b.chunk_len, b.chunk_base, b.bits, b.status};
-    hipLaunchKernelGGL((k_entropy<false>), dim3(grid), dim3(ENT_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, b.chunk_len, nchunks, b.chunk_base, b.status, b.bits);
-    hipLaunchKernelGGL((k_entropy<true>), dim3(grid), dim3(ENT_THREADS), 0, s, a);
+    EntArgs a{coef, g.nblocks, nchunks, g.nb, g.h * g.v, {pred[0], pred[1], pred[2]}, b.epoch, b.agg, b.grp, b.hyp, b.tail,
+              b.ticket, b.bits, b.status};
+    hipLaunchKernelGGL(k_entropy, dim3(grid), dim3(ENT_THREADS), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s) {
-    StuffArgs a{b.bits, b.status, (uint32_t)(bit_offset & 7), head_bits, is_last, b.seg_cnt, b.seg_off, b.scan};
+    StuffArgs a{b.bits, b.status, (uint32_t)(bit_offset & 7), head_bits, is_last, b.seg_cnt, b.seg_off, b.scan, b.host_status};
     const size_t max_seg = b.nseg_cap;
     const unsigned grid = (unsigned)(max_seg < 2048 ? (max_seg ? max_seg : 1) : 2048);
     hipLaunchKernelGGL(k_ff_count, dim3(grid), dim3(256), 0, s, a);

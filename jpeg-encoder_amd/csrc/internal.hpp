@@ -46,10 +46,16 @@ struct DevStatus {
 };
 
 struct EntropyBufs {
-    uint16_t *blk_bits;    // [nblocks] coded bits of each block
-    uint32_t *chunk_len;   // [nchunks] bits of each chunk
-    uint64_t *chunk_base;  // [nchunks] bit offset of the chunk in the stream
+    // per-chunk hand-off words of the single-pass scan (see entropy.hip); each is
+    // {epoch:14 | valid:1 | value:49} written by one 8-byte store
+    uint64_t *agg;         // [nchunks] bits of the chunk
+    uint64_t *grp;         // [nchunks/64] bits of a group of 64 chunks
+    uint64_t *hyp;         // [nchunks/4096] bits of a hyper-group of 64 groups
+    uint64_t *tail;        // [nchunks] last 32 bits of the chunk
+    uint32_t *ticket;      // [1] next chunk to hand out; the last taker resets it to 0
+    uint32_t epoch;        // generation of the words above (host side, 1..16383)
     DevStatus *status;
+    DevStatus *host_status;  // pinned host copy the last kernel fills (may be null)
     uint32_t *bits;        // unstuffed MSB-first stream, as 32-bit words in memory byte order
     size_t bits_cap;       // bytes
     uint32_t *seg_cnt;     // [nseg_cap] 0xFF bytes per stuffing segment
