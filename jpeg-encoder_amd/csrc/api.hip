@@ -124,8 +124,12 @@ extern "C" int jpg_create(jpg_ctx **out, int device, int dct_algo, int ra, int r
               hipHostMalloc((void **)&c->h_dc, 4 * sizeof(int16_t), hipHostMallocDefault) == hipSuccess &&
               hipMalloc((void **)&c->d_dc, 4 * sizeof(int16_t)) == hipSuccess &&
               hipMalloc((void **)&c->eb.status, sizeof(DevStatus)) == hipSuccess &&
-              hipMalloc((void **)&c->eb.ticket, sizeof(uint32_t)) == hipSuccess &&
-              hipMemset(c->eb.ticket, 0, sizeof(uint32_t)) == hipSuccess;
+              hipMemset(c->eb.status, 0, sizeof(DevStatus)) == hipSuccess;
+    if (ok) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        c->eb.stuff_grid = (size_t)cus * 4;
+    }
     if (!ok) {
         (void)hipGetLastError();
         jpg_destroy(c);
@@ -140,8 +144,8 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_src_own, c->d_plane[0], c->d_plane[1], c->d_plane[2], c->d_down[0], c->d_down[1], c->d_coef,
-                   c->d_tmp16, c->d_dc, c->eb.agg, c->eb.grp, c->eb.hyp, c->eb.tail, c->eb.ticket, c->eb.status,
-                   c->eb.bits, c->eb.seg_cnt, c->eb.seg_off, c->eb.scan};
+                   c->d_tmp16, c->d_dc, c->eb.agg, c->eb.grp, c->eb.hyp, c->eb.tail, c->eb.status,
+                   c->eb.bits, c->eb.sagg, c->eb.sgrp, c->eb.shyp, c->eb.scan};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -207,8 +211,10 @@ static int ensure_entropy(jpg_ctx *c) {
     c->hw_cap = nchunks;
     c->eb.epoch = 0;   // forces the hand-off words to be cleared before first use
     if ((e = re(c->eb.bits, bits_bytes / 4))) return e;
-    if ((e = re(c->eb.seg_cnt, nseg))) return e;
-    if ((e = re(c->eb.seg_off, nseg))) return e;
+    if ((e = re(c->eb.sagg, nseg))) return e;
+    if ((e = re(c->eb.sgrp, nseg / 64 + 1))) return e;
+    if ((e = re(c->eb.shyp, nseg / 4096 + 1))) return e;
+    c->eb.stuff_epoch = 0;
     if ((e = re(c->eb.scan, scan_bytes))) return e;
     c->eb.bits_cap = bits_bytes;
     c->eb.scan_cap = scan_bytes;
@@ -304,13 +310,34 @@ static int queue_entropy(jpg_ctx *c, const int16_t pred[3]) {
         HIP_TRY(c, hipMemsetAsync(c->eb.grp, 0, (c->hw_cap / 64 + 1) * sizeof(uint64_t), c->stream));
         HIP_TRY(c, hipMemsetAsync(c->eb.hyp, 0, (c->hw_cap / 4096 + 1) * sizeof(uint64_t), c->stream));
         HIP_TRY(c, hipMemsetAsync(c->eb.tail, 0, c->hw_cap * sizeof(uint64_t), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->eb.ticket, 0, sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->eb.status, 0, sizeof(DevStatus), c->stream));
         c->eb.epoch = 0;
     }
     c->eb.epoch++;
     c->eb.host_status = c->h_status;
     static const int16_t zero[3] = {0, 0, 0};   // src/jpeg/entropy_coding.rs:38-40
     HIP_TRY(c, launch_entropy(c->g, c->d_coef, pred ? pred : zero, c->eb, c->stream));
+    return JPG_OK;
+}
+
+// queue the stuffing kernel (new generation of its hand-off words per launch)
+static int queue_stuff(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, int is_last) {
+    if (c->eb.stuff_epoch == 0 || c->eb.stuff_epoch >= 16383) {
+        HIP_TRY(c, hipMemsetAsync(c->eb.sagg, 0, c->eb.nseg_cap * sizeof(uint64_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->eb.sgrp, 0, (c->eb.nseg_cap / 64 + 1) * sizeof(uint64_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->eb.shyp, 0, (c->eb.nseg_cap / 4096 + 1) * sizeof(uint64_t), c->stream));
+        c->eb.stuff_epoch = 0;
+    }
+    c->eb.stuff_epoch++;
+    c->eb.host_status = c->h_status;
+    HIP_TRY(c, launch_stuff(c->eb, bit_offset, head_bits, is_last, c->stream));
+    return JPG_OK;
+}
+
+// status word of the last launch: 0 or the jpg_status a kernel raised
+static int kernel_error(const jpg_ctx *c) {
+    const int v = -c->h_status->error;
+    if (v > 0 && (uint32_t)(v >> 8) == c->eb.epoch) return -(v & 0xff);
     return JPG_OK;
 }
 
@@ -326,7 +353,7 @@ static int entropy_common(jpg_ctx *c, const int16_t *pred, uint64_t *nbits) {
     if (int e = queue_entropy(c, pred)) return e;
     if (int e = fetch_status(c)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->h_status->error) return c->h_status->error;
+    if (int ke = kernel_error(c)) return ke;
     c->nbits = c->h_status->nbits;
     if (nbits) *nbits = c->nbits;
     c->stage = ST_BITS;
@@ -354,9 +381,9 @@ extern "C" int jpg_stitch(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, in
     if (!c) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_BITS) return JPG_ERR_STATE;
     if (int e = use_device(c)) return e;
-    HIP_TRY(c, launch_stuff(c->eb, bit_offset, head_bits, is_last, c->stream));
-    if (int e = fetch_status(c)) return e;
+    if (int e = queue_stuff(c, bit_offset, head_bits, is_last)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int ke = kernel_error(c)) return ke;
     c->scan_len = (size_t)c->h_status->scan_bytes;
     if (len) *len = c->scan_len;
     if (tail) *tail = (uint8_t)c->h_status->tail;
@@ -382,8 +409,7 @@ extern "C" int jpg_encode_device_async(jpg_ctx *c, const uint8_t *dev_pixels, in
                                        int bottom_up) {
     if (int e = jpg_front_device(c, dev_pixels, W, H, stride, bottom_up)) return e;
     if (int e = queue_entropy(c, nullptr)) return e;
-    HIP_TRY(c, launch_stuff(c->eb, 0, 0, 1, c->stream));
-    if (int e = fetch_status(c)) return e;
+    if (int e = queue_stuff(c, 0, 0, 1)) return e;
     c->pending = true;
     return JPG_OK;
 }
@@ -394,7 +420,7 @@ extern "C" int jpg_finish(jpg_ctx *c, uint64_t *nbits, size_t *stuffed_len) {
     if (int e = use_device(c)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->pending = false;
-    if (c->h_status->error) return c->h_status->error;
+    if (int ke = kernel_error(c)) return ke;
     c->nbits = c->h_status->nbits;
     c->scan_len = (size_t)c->h_status->scan_bytes;
     if (nbits) *nbits = c->nbits;
@@ -414,8 +440,7 @@ extern "C" int jpg_encode_scan(jpg_ctx *c, const uint8_t *pixels, int32_t W, int
     HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream));
     c->stage = ST_COEF;
     if (int e = queue_entropy(c, nullptr)) return e;
-    HIP_TRY(c, launch_stuff(c->eb, 0, 0, 1, c->stream));
-    if (int e = fetch_status(c)) return e;
+    if (int e = queue_stuff(c, 0, 0, 1)) return e;
     c->pending = true;
     if (int e = jpg_finish(c, nullptr, nullptr)) return e;
     void *host = nullptr;

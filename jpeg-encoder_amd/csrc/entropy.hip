@@ -19,7 +19,7 @@
 // A wave only ever waits for chunks with a lower number, which belong to
 // workgroups dispatched before its own.
 //
-// k_ff_count / k_ff_scan / k_ff_scatter then insert 0x00 after every 0xFF.
+// k_stuff then inserts 0x00 after every 0xFF, placing its segments the same way.
 #include "../../include/jpeg_hip.h"
 #include "internal.hpp"
 #include "tables.h"
@@ -28,7 +28,10 @@ namespace jpg {
 
 __device__ const jpgtab::HuffLut HUFF_DEV{};
 constexpr int LUT_WORDS = 2 * jpgtab::HUFF_LUT_STRIDE;
-constexpr int ENT_THREADS = 128;
+#ifndef JPG_ENT_THREADS
+#define JPG_ENT_THREADS 128
+#endif
+constexpr int ENT_THREADS = JPG_ENT_THREADS;
 constexpr int ENT_WAVES = ENT_THREADS / 64;
 constexpr uint32_t SPIN_LIMIT = 1u << 22;       // polls before a wave gives up waiting (never hang the GPU)
 constexpr int SLOT_BYTES = 144;                 // 128-byte block + 16: conflict-free 16-byte LDS access
@@ -52,10 +55,15 @@ struct EntArgs {
     int16_t pred[3];
     uint32_t epoch;
     uint64_t *agg, *grp, *hyp, *tail;
-    uint32_t *ticket;
     uint32_t *bits;
     DevStatus *status;
 };
+
+// Errors are recorded as -(epoch << 8 | code) with atomicMin, so a newer launch always
+// overrides an older one and the word never needs clearing between launches.
+__device__ __forceinline__ void raise_error(DevStatus *st, uint32_t epoch, int status_code) {
+    atomicMin(&st->error, -(int)((epoch << 8) | (uint32_t)(-status_code)));
+}
 
 // hand-off word: {epoch:14 | valid:1 | value:49}
 __device__ __forceinline__ uint64_t hw_pack(uint32_t epoch, uint64_t value) {
@@ -103,12 +111,12 @@ struct NullWriter {
 // set where coefficient k is non-zero (k >= 1).  Returns the coded length.
 template <class W>
 __device__ __forceinline__ uint32_t code_block(const uint16_t *slot, uint32_t mlo, uint32_t mhi, int dc_diff,
-                                               const uint32_t *lut, int *error, W &w) {
+                                               const uint32_t *lut, DevStatus *st, uint32_t epoch, W &w) {
     // DC: size = bit length of |diff| (src/jpeg/entropy_coding.rs:127-134,149-160)
     uint32_t mag = (uint32_t)(dc_diff < 0 ? -dc_diff : dc_diff);
     uint32_t size = 32 - __clz(mag);
     if (size > 11) {
-        atomicMin(error, (int)JPG_ERR_DC_RANGE);
+        raise_error(st, epoch, JPG_ERR_DC_RANGE);
         size = 0;
     }
     // negative values: v + (1 << size) - 1 (src/jpeg/entropy_coding.rs:140-142)
@@ -135,7 +143,7 @@ __device__ __forceinline__ uint32_t code_block(const uint16_t *slot, uint32_t ml
             mag = (uint32_t)(v < 0 ? -v : v);
             size = 32 - __clz(mag);
             if (size > 10) {
-                atomicMin(error, (int)JPG_ERR_AC_RANGE);
+                raise_error(st, epoch, JPG_ERR_AC_RANGE);
                 size = 0;
             }
             amp = (uint32_t)(v < 0 ? v - 1 : v) & ((1u << size) - 1u);
@@ -170,51 +178,75 @@ __device__ __forceinline__ void nonzero_mask(const uint4 (&q)[8], uint32_t &mlo,
     mhi = m[1];
 }
 
-// poll a hand-off word until it carries this launch's epoch
-__device__ __forceinline__ uint64_t hw_wait(const uint64_t *p, bool need, uint32_t epoch, bool &timeout) {
-    uint64_t w = 0;
-    bool ok = !need;
+// Three levels of running sums over items 0..n-1 (chunks of blocks here, segments
+// of bytes in the stuffing kernel), each word {epoch | valid | value}:
+//   agg[i]  value of item i                (published by i as soon as it is known)
+//   grp[g]  sum of items 64g..64g+63       (published by the last item of the group)
+//   hyp[h]  sum of groups 64h..64h+63      (published by the last item of the hyper-group)
+// prefix(i) = sum hyp[< h] + sum grp[64h .. g-1] + sum agg[64g .. i-1].  Every sum is
+// published as soon as it is known and before its publisher waits for anything else, so
+// the publications never form a chain; an item only waits for items with a lower number.
+struct Sums {
+    uint64_t *agg, *grp, *hyp;
+    uint32_t epoch;
+    long long n;
+};
+
+// words fetched ahead of time (they may not be valid yet)
+struct Probe {
+    uint64_t wa, wg, wh;
+};
+
+__device__ __forceinline__ Probe sums_probe(const Sums &s, long long i, int lane) {
+    const long long g = i >> 6, h = g >> 6;
+    Probe p{0, 0, 0};
+    if ((g << 6) + lane < i) p.wa = hw_load(&s.agg[(g << 6) + lane]);
+    if ((h << 6) + lane < g) p.wg = hw_load(&s.grp[(h << 6) + lane]);
+    if (lane < h) p.wh = hw_load(&s.hyp[lane]);
+    return p;
+}
+
+// poll a hand-off word until it carries this launch's epoch; `w` is an earlier look at it
+__device__ __forceinline__ uint64_t hw_wait(const uint64_t *p, bool need, uint64_t w, uint32_t epoch, bool &timeout) {
+    bool ok = !need || hw_valid(w, epoch);
     for (uint32_t spin = 0;; spin++) {
+        if (__ballot(!ok) == 0) break;
+        if (spin >= SPIN_LIMIT) { timeout = true; break; }
+        if (spin) __builtin_amdgcn_s_sleep(1);
         if (!ok) {
             w = hw_load(p);
             ok = hw_valid(w, epoch);
         }
-        if (__ballot(!ok) == 0) break;
-        if (spin >= SPIN_LIMIT) { timeout = true; break; }
-        __builtin_amdgcn_s_sleep(1);
     }
     return need && ok ? hw_value(w) : 0;
 }
 
-// Bit offset of chunk `chunk` in the stream = sum of the lengths of all chunks
-// before it, gathered from three levels of sums so that no wave waits on a chain:
-//   agg[c]  bits of chunk c            (published by c right after measuring)
-//   grp[g]  bits of chunks 64g..64g+63 (published by the last chunk of the group)
-//   hyp[h]  bits of groups 64h..64h+63 (published by the last chunk of the hyper-group)
-// offset(c) = sum hyp[< h] + sum grp[64h .. g-1] + sum agg[64g .. c-1].  The wave
-// that closes a group or hyper-group publishes its sum from the same partial sums.
-__device__ __forceinline__ uint64_t chunk_offset(const EntArgs &a, long long chunk, uint32_t total, int lane,
-                                                 bool &timeout) {
-    const long long g = chunk >> 6, h = g >> 6;
-    const bool closes_group = (chunk & 63) == 63 || chunk == a.nchunks - 1;
-    const bool closes_hyper = closes_group && ((g & 63) == 63 || chunk == a.nchunks - 1);
-    // each sum is published as soon as it is known, before waiting for anything else,
-    // so the publications never form a chain
-    const long long ia = (g << 6) + lane;
-    const uint32_t sum_a = __shfl(wave_incl_scan((uint32_t)hw_wait(&a.agg[ia], ia < chunk, a.epoch, timeout)), 63);
-    const uint64_t gv = (uint64_t)sum_a + total;
-    if (closes_group && lane == 0) hw_store(&a.grp[g], hw_pack(a.epoch, gv));
-    const long long ig = (h << 6) + lane;
-    const uint32_t sum_g = __shfl(wave_incl_scan((uint32_t)hw_wait(&a.grp[ig], ig < g, a.epoch, timeout)), 63);
-    if (closes_hyper && lane == 0) hw_store(&a.hyp[h], hw_pack(a.epoch, (uint64_t)sum_g + gv));
-    uint64_t sh = 0;
-    for (long long j0 = 0; j0 < h; j0 += 64) sh += hw_wait(&a.hyp[j0 + lane], j0 + lane < h, a.epoch, timeout);
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
-        const uint32_t lo = __shfl_xor((uint32_t)sh, d), hi = __shfl_xor((uint32_t)(sh >> 32), d);
-        sh += ((uint64_t)hi << 32) | lo;
+        const uint32_t lo = __shfl_xor((uint32_t)v, d), hi = __shfl_xor((uint32_t)(v >> 32), d);
+        v += ((uint64_t)hi << 32) | lo;
     }
-    return sh + sum_g + sum_a;
+    return v;
+}
+
+// exclusive prefix of item i whose own value is `own`; called by a whole wave
+__device__ __forceinline__ uint64_t sums_prefix(const Sums &s, long long i, uint64_t own, const Probe &pr, int lane,
+                                                bool &timeout) {
+    const long long g = i >> 6, h = g >> 6;
+    const bool closes_group = (i & 63) == 63 || i == s.n - 1;
+    const bool closes_hyper = closes_group && ((g & 63) == 63 || i == s.n - 1);
+    const long long ia = (g << 6) + lane;
+    const uint64_t sum_a = wave_sum64(hw_wait(&s.agg[ia], ia < i, pr.wa, s.epoch, timeout));
+    const uint64_t gv = sum_a + own;
+    if (closes_group && lane == 0) hw_store(&s.grp[g], hw_pack(s.epoch, gv));
+    const long long ig = (h << 6) + lane;
+    const uint64_t sum_g = wave_sum64(hw_wait(&s.grp[ig], ig < g, pr.wg, s.epoch, timeout));
+    if (closes_hyper && lane == 0) hw_store(&s.hyp[h], hw_pack(s.epoch, sum_g + gv));
+    uint64_t sh = 0;
+    for (long long j0 = 0; j0 < h; j0 += 64)
+        sh += hw_wait(&s.hyp[j0 + lane], j0 + lane < h, j0 ? 0 : pr.wh, s.epoch, timeout);
+    return wave_sum64(sh) + sum_g + sum_a;
 }
 
 __global__ __launch_bounds__(ENT_THREADS) void k_entropy(EntArgs a) {
@@ -270,9 +302,10 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy(EntArgs a) {
 
     // 1. lengths
     NullWriter nw;
-    const uint32_t len = valid ? code_block(slot, mlo, mhi, dc_diff, lut, &a.status->error, nw) : 0u;
+    const uint32_t len = valid ? code_block(slot, mlo, mhi, dc_diff, lut, a.status, a.epoch, nw) : 0u;
     const uint32_t sc = wave_incl_scan(len);                      // bits up to and including this lane's block
     const uint32_t total = __shfl(sc, 63);
+    const Sums sums{a.agg, a.grp, a.hyp, a.epoch, a.nchunks};
     if (lane == 0) hw_store(&a.agg[chunk], hw_pack(a.epoch, total));
 
     // 2..4. code and write out; a chunk too long for the LDS window goes in several passes
@@ -292,7 +325,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy(EntArgs a) {
         if (mine) {
             BitWriter w;
             w.init(out, sc - len - done);
-            code_block(slot, mlo, mhi, dc_diff, lut, &a.status->error, w);
+            code_block(slot, mlo, mhi, dc_diff, lut, a.status, a.epoch, w);
         }
         __builtin_amdgcn_wave_barrier();
         const bool last_pass = done + pass_bits >= total;
@@ -308,27 +341,14 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy(EntArgs a) {
         if (last_pass && lane == 0) hw_store(&a.tail[chunk], hw_pack(a.epoch, new_tail));
         if (pass == 0) {
             // 3. where does the chunk start?
-#if defined(JPG_ENT_NOWAIT) && (JPG_ENT_NOWAIT & 1)
-            O = (uint64_t)chunk * 4096;
-#else
-            O = chunk_offset(a, chunk, total, lane, timeout);
-#endif
-#if defined(JPG_ENT_NOWAIT) && (JPG_ENT_NOWAIT & 2)
-            if (false) {
-#else
+            // (looking at the predecessors' words any earlier only adds traffic: measured slower)
+            O = sums_prefix(sums, chunk, total, Probe{0, 0, 0}, lane, timeout);
             if (chunk > 0) {
-#endif
-                uint64_t tw = 0;
-                for (uint32_t spin = 0; lane == 0; spin++) {
-                    tw = hw_load(&a.tail[chunk - 1]);
-                    if (hw_valid(tw, a.epoch)) break;
-                    if (spin >= SPIN_LIMIT) { timeout = true; break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                prev_tail = __shfl((uint32_t)hw_value(tw), 0);
+                const uint64_t tail_word = hw_wait(&a.tail[chunk - 1], lane == 0, 0, a.epoch, timeout);
+                prev_tail = __shfl((uint32_t)tail_word, 0);
             }
             if (chunk == a.nchunks - 1 && lane == 0) a.status->nbits = O + total;
-            if (__ballot(timeout) && lane == 0) atomicMin(&a.status->error, (int)JPG_ERR_HIP);
+            if (__ballot(timeout) && lane == 0) raise_error(a.status, a.epoch, JPG_ERR_HIP);
         }
         // 4. write the pass at bit O + done: word i = stream bits, preceded by prev_tail
         const uint64_t P = O + done;
@@ -349,46 +369,6 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy(EntArgs a) {
     }
 }
 
-// Exclusive scan of n 32-bit values by one workgroup of 1024 threads:
-// emit(i, offset, value) is called once per entry, the total is returned.
-// Rounds of 1024 consecutive entries (coalesced), eight rounds of loads in
-// flight at a time; each round is a wave scan plus a 16-entry LDS scan.
-template <class Emit>
-__device__ __forceinline__ uint64_t block_scan_1024(const uint32_t *__restrict__ len, long long n, Emit emit) {
-    __shared__ uint32_t s[2][16];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    uint64_t carry = 0;
-    constexpr int B = 8;
-    int buf = 0;
-    for (long long r0 = 0; r0 < n; r0 += 1024LL * B) {
-        uint32_t L[B];
-#pragma unroll
-        for (int r = 0; r < B; r++) {
-            const long long i = r0 + 1024LL * r + tid;
-            L[r] = i < n ? len[i] : 0u;
-        }
-#pragma unroll
-        for (int r = 0; r < B; r++) {
-            const long long i = r0 + 1024LL * r + tid;
-            if (r0 + 1024LL * r >= n) break;                     // uniform
-            const uint32_t sc = wave_incl_scan(L[r]);
-            if (lane == 63) s[buf][wave] = sc;
-            __syncthreads();
-            uint32_t before = 0, all = 0;
-#pragma unroll
-            for (int w = 0; w < 16; w++) {
-                const uint32_t t = s[buf][w];
-                before += w < wave ? t : 0u;
-                all += t;
-            }
-            buf ^= 1;                                            // next round writes the other copy: one barrier per round
-            if (i < n) emit(i, carry + before + (sc - L[r]), L[r]);
-            carry += all;
-        }
-    }
-    return carry;
-}
-
 // ---------------------------------------------------------------- stuffing
 
 struct StuffArgs {
@@ -397,10 +377,11 @@ struct StuffArgs {
     uint32_t shift;          // place the stream `shift` (0..7) bits later
     uint32_t head;           // bits OR-ed into the first byte (top `shift` bits)
     int is_last;             // keep the trailing partial byte
-    uint32_t *seg_cnt;
-    uint64_t *seg_off;
+    uint64_t *agg, *grp, *hyp;  // three-level sums of 0xFF counts per segment
+    uint32_t epoch;          // generation of those words
+    uint32_t err_epoch;      // epoch errors are tagged with (that of the entropy launch)
     uint8_t *out;
-    DevStatus *host_status;  // pinned host copy, filled by the last kernel (may be null)
+    DevStatus *host_status;  // pinned host copy, filled at the end (may be null)
 };
 
 __device__ __forceinline__ uint64_t shifted_bytes(const StuffArgs &a) {
@@ -437,52 +418,22 @@ __device__ __forceinline__ uint32_t count_ff(uint32_t w) {
     return __popc(t);
 }
 
-__global__ __launch_bounds__(256) void k_ff_count(StuffArgs a) {
+// Byte stuffing in one pass: a workgroup takes segments of STUFF_SEG input bytes
+// (blockIdx.x, + gridDim.x, ...), counts their 0xFF bytes, learns how many precede the
+// segment from the three-level sums, and writes the segment with 0x00 after every 0xFF.
+__global__ __launch_bounds__(256) void k_stuff(StuffArgs a) {
     __shared__ uint32_t s[4];
-    const uint64_t in_bytes = (a.status->nbits + 7) >> 3;
-    const uint64_t nbytes = shifted_bytes(a);
-    const uint64_t nseg = (nbytes + STUFF_SEG - 1) / STUFF_SEG;
-    for (uint64_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        const uint64_t q = seg * (STUFF_SEG / 16) + threadIdx.x;
-        uint32_t t[4];
-        load16(a, q, in_bytes, t);
-        uint32_t c = 0;
-        if (16 * q < nbytes) c = count_ff(t[0]) + count_ff(t[1]) + count_ff(t[2]) + count_ff(t[3]);
-        const uint32_t sc = wave_incl_scan(c);
-        if ((threadIdx.x & 63) == 63) s[threadIdx.x >> 6] = sc;
-        __syncthreads();
-        if (threadIdx.x == 0) a.seg_cnt[seg] = s[0] + s[1] + s[2] + s[3];
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_ff_scan(StuffArgs a) {
-    const uint64_t nbytes = shifted_bytes(a);
-    const long long n = (long long)((nbytes + STUFF_SEG - 1) / STUFF_SEG);
-    const uint64_t total = block_scan_1024(a.seg_cnt, n, [&](long long i, uint64_t off, uint32_t) {
-        a.seg_off[i] = (uint64_t)i * STUFF_SEG + off;
-    });
-    if (threadIdx.x == 0) {
-        a.status->scan_bytes = nbytes + total;
-        // bits of the partial byte a non-final stripe leaves to its successor
-        const uint64_t tbits = a.status->nbits + a.shift;
-        uint32_t tail = 0;
-        if (!a.is_last && (tbits & 7)) {
-            const uint64_t in_bytes = (a.status->nbits + 7) >> 3;
-            uint32_t t[4];
-            load16(a, nbytes >> 4, in_bytes, t);
-            tail = (t[(nbytes >> 2) & 3] >> (24 - 8 * (nbytes & 3))) & 0xffu;
-        }
-        a.status->tail = tail;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_ff_scatter(StuffArgs a) {
-    __shared__ uint32_t s[4];
+    __shared__ uint64_t sBefore;
     const uint64_t in_bytes = (a.status->nbits + 7) >> 3;
     const uint64_t nbytes = shifted_bytes(a);
     const uint64_t nseg = (nbytes + STUFF_SEG - 1) / STUFF_SEG;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Sums sums{a.agg, a.grp, a.hyp, a.epoch, (long long)nseg};
+    if (nseg == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.status->scan_bytes = 0;
+        a.status->tail = 0;
+        if (a.host_status) *a.host_status = *a.status;
+    }
     for (uint64_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
         const uint64_t q = seg * (STUFF_SEG / 16) + threadIdx.x;
         uint32_t t[4];
@@ -492,9 +443,34 @@ __global__ __launch_bounds__(256) void k_ff_scatter(StuffArgs a) {
         const uint32_t sc = wave_incl_scan(c);
         if (lane == 63) s[wave] = sc;
         __syncthreads();
+        const uint32_t total = s[0] + s[1] + s[2] + s[3];
+        if (wave == 0) {
+            bool timeout = false;
+            if (lane == 0) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
+            const Probe probe = sums_probe(sums, (long long)seg, lane);
+            const uint64_t before = sums_prefix(sums, (long long)seg, total, probe, lane, timeout);
+            if (lane == 0) {
+                sBefore = before;
+                if (timeout) raise_error(a.status, a.err_epoch, JPG_ERR_HIP);
+                if (seg == nseg - 1) {
+                    a.status->scan_bytes = nbytes + before + total;
+                    // bits of the partial byte a non-final stripe leaves to its successor
+                    const uint64_t tbits = a.status->nbits + a.shift;
+                    uint32_t tail = 0;
+                    if (!a.is_last && (tbits & 7)) {
+                        uint32_t u[4];
+                        load16(a, nbytes >> 4, in_bytes, u);
+                        tail = (u[(nbytes >> 2) & 3] >> (24 - 8 * (nbytes & 3))) & 0xffu;
+                    }
+                    a.status->tail = tail;
+                    if (a.host_status) *a.host_status = *a.status;
+                }
+            }
+        }
+        __syncthreads();
         uint32_t before = sc - c;
         for (int w = 0; w < wave; w++) before += s[w];
-        uint8_t *o = a.out + a.seg_off[seg] + 16 * threadIdx.x + before;
+        uint8_t *o = a.out + seg * STUFF_SEG + sBefore + 16 * threadIdx.x + before;
         if (16 * q + 16 <= nbytes && c == 0 && ((reinterpret_cast<uintptr_t>(o) & 3) == 0)) {
             // common case: 16 plain bytes, destination word-aligned
             uint32_t *o4 = reinterpret_cast<uint32_t *>(o);
@@ -512,28 +488,24 @@ __global__ __launch_bounds__(256) void k_ff_scatter(StuffArgs a) {
         }
         __syncthreads();
     }
-    if (a.host_status && blockIdx.x == 0 && threadIdx.x == 0) *a.host_status = *a.status;
 }
 
 hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred[3], const EntropyBufs &b,
                           hipStream_t s) {
     const long long nchunks = (g.nblocks + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
     const unsigned grid = (unsigned)((nchunks + ENT_WAVES - 1) / ENT_WAVES);
-    hipError_t e = hipMemsetAsync(b.status, 0, sizeof(DevStatus), s);
-    if (e != hipSuccess) return e;
     EntArgs a{coef, g.nblocks, nchunks, g.nb, g.h * g.v, {pred[0], pred[1], pred[2]}, b.epoch, b.agg, b.grp, b.hyp, b.tail,
-              b.ticket, b.bits, b.status};
+              b.bits, b.status};
     hipLaunchKernelGGL(k_entropy, dim3(grid), dim3(ENT_THREADS), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s) {
-    StuffArgs a{b.bits, b.status, (uint32_t)(bit_offset & 7), head_bits, is_last, b.seg_cnt, b.seg_off, b.scan, b.host_status};
-    const size_t max_seg = b.nseg_cap;
-    const unsigned grid = (unsigned)(max_seg < 2048 ? (max_seg ? max_seg : 1) : 2048);
-    hipLaunchKernelGGL(k_ff_count, dim3(grid), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_ff_scan, dim3(1), dim3(1024), 0, s, a);
-    hipLaunchKernelGGL(k_ff_scatter, dim3(grid), dim3(256), 0, s, a);
+    StuffArgs a{b.bits, b.status, (uint32_t)(bit_offset & 7), head_bits, is_last, b.sagg, b.sgrp, b.shyp, b.stuff_epoch,
+                b.epoch, b.scan, b.host_status};
+    const size_t cap = b.stuff_grid ? b.stuff_grid : 1024;
+    const unsigned grid = (unsigned)(b.nseg_cap < cap ? (b.nseg_cap ? b.nseg_cap : 1) : cap);
+    hipLaunchKernelGGL(k_stuff, dim3(grid), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -52,14 +52,14 @@ struct EntropyBufs {
     uint64_t *grp;         // [nchunks/64] bits of a group of 64 chunks
     uint64_t *hyp;         // [nchunks/4096] bits of a hyper-group of 64 groups
     uint64_t *tail;        // [nchunks] last 32 bits of the chunk
-    uint32_t *ticket;      // [1] next chunk to hand out; the last taker resets it to 0
     uint32_t epoch;        // generation of the words above (host side, 1..16383)
     DevStatus *status;
     DevStatus *host_status;  // pinned host copy the last kernel fills (may be null)
     uint32_t *bits;        // unstuffed MSB-first stream, as 32-bit words in memory byte order
     size_t bits_cap;       // bytes
-    uint32_t *seg_cnt;     // [nseg_cap] 0xFF bytes per stuffing segment
-    uint64_t *seg_off;     // [nseg_cap] output byte offset of each segment
+    uint64_t *sagg, *sgrp, *shyp;  // the same three levels for the 0xFF counts of the stuffing segments
+    uint32_t stuff_epoch;  // their generation (1..16383)
+    size_t stuff_grid;     // workgroups of the stuffing kernel (all must be able to be resident)
     uint8_t *scan;         // stuffed stream
     size_t scan_cap;
     size_t nseg_cap;
