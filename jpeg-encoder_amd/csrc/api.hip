@@ -22,6 +22,7 @@ struct jpg_ctx {
     bool have_planes = false;   // staged u8 planes are valid
     bool down_done = false;
     bool pending = false;       // an async encode awaits jpg_finish
+    bool dense_valid = false;   // eb.bits holds the dense stream of the last entropy launch
     Geom g{};
 
     uint8_t *d_src_own = nullptr; size_t src_cap = 0;
@@ -33,7 +34,6 @@ struct jpg_ctx {
     int16_t *d_dc = nullptr;     // last DCs out (3 values)
     EntropyBufs eb{};
     size_t ent_cap = 0;          // in blocks
-    size_t hw_cap = 0;           // hand-off words per array
     DevStatus *h_status = nullptr;  // pinned copy of eb.status
     int16_t *h_dc = nullptr;        // pinned
     uint64_t nbits = 0;
@@ -144,7 +144,7 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_src_own, c->d_plane[0], c->d_plane[1], c->d_plane[2], c->d_down[0], c->d_down[1], c->d_coef,
-                   c->d_tmp16, c->d_dc, c->eb.agg, c->eb.grp, c->eb.hyp, c->eb.tail, c->eb.status,
+                   c->d_tmp16, c->d_dc, c->eb.clen, c->eb.sparse, c->eb.status,
                    c->eb.bits, c->eb.sagg, c->eb.sgrp, c->eb.shyp, c->eb.scan};
     for (void *p : dev)
         if (p) (void)hipFree(p);
@@ -185,41 +185,52 @@ static int ensure_coef(jpg_ctx *c) {
     return grow(c, c->d_coef, c->coef_cap, nblk * 64);
 }
 
+// worst case of the unstuffed stream: every block at its maximum coded size
+static size_t worst_bits_bytes(size_t nblk) {
+    const size_t b = (nblk * MAX_BLOCK_BITS + 7) / 8 + 64;
+    return (b + 15) / 16 * 16;
+}
+
+template <class T>
+static int regrow(jpg_ctx *c, T *&p, size_t n) {
+    size_t cap = 0;
+    if (p) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(p);
+        p = nullptr;
+    }
+    return grow(c, p, cap, n);
+}
+
 static int ensure_entropy(jpg_ctx *c) {
     const size_t nblk = (size_t)c->g.nblocks;
-    if (nblk <= c->ent_cap) return JPG_OK;
     const size_t nchunks = (nblk + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
-    // worst case: every block at its maximum coded size
-    size_t bits_bytes = (nblk * MAX_BLOCK_BITS + 7) / 8 + 64;
-    bits_bytes = (bits_bytes + 15) / 16 * 16;
+    if ((nchunks + 63) / 64 > (size_t)MAX_GROUPS) return JPG_ERR_CAPACITY;
+    c->eb.nchunks = (long long)nchunks;
+    if (nblk <= c->ent_cap) return JPG_OK;
+    const size_t bits_bytes = worst_bits_bytes(nblk);
     const size_t scan_bytes = 2 * bits_bytes + 16;
     const size_t nseg = bits_bytes / STUFF_SEG + 2;
     int e;
-    auto re = [&](auto *&p, size_t n) -> int {
-        size_t cc = 0;
-        if (p) {
-            (void)hipStreamSynchronize(c->stream);
-            (void)hipFree(p);
-            p = nullptr;
-        }
-        return grow(c, p, cc, n);
-    };
-    if ((e = re(c->eb.agg, nchunks))) return e;
-    if ((e = re(c->eb.grp, nchunks / 64 + 1))) return e;
-    if ((e = re(c->eb.hyp, nchunks / 4096 + 1))) return e;
-    if ((e = re(c->eb.tail, nchunks))) return e;
-    c->hw_cap = nchunks;
-    c->eb.epoch = 0;   // forces the hand-off words to be cleared before first use
-    if ((e = re(c->eb.bits, bits_bytes / 4))) return e;
-    if ((e = re(c->eb.sagg, nseg))) return e;
-    if ((e = re(c->eb.sgrp, nseg / 64 + 1))) return e;
-    if ((e = re(c->eb.shyp, nseg / 4096 + 1))) return e;
-    c->eb.stuff_epoch = 0;
-    if ((e = re(c->eb.scan, scan_bytes))) return e;
-    c->eb.bits_cap = bits_bytes;
+    if ((e = regrow(c, c->eb.clen, (nchunks + 63) / 64 * 64))) return e;
+    if ((e = regrow(c, c->eb.sparse, nchunks * CHUNK_STRIDE_WORDS))) return e;
+    if ((e = regrow(c, c->eb.sagg, nseg))) return e;
+    if ((e = regrow(c, c->eb.sgrp, nseg / 64 + 1))) return e;
+    if ((e = regrow(c, c->eb.shyp, nseg / 4096 + 1))) return e;
+    c->eb.stuff_epoch = 0;   // forces the hand-off words to be cleared before first use
+    if ((e = regrow(c, c->eb.scan, scan_bytes))) return e;
     c->eb.scan_cap = scan_bytes;
     c->eb.nseg_cap = nseg;
     c->ent_cap = nblk;
+    return JPG_OK;
+}
+
+// the dense copy of the stream is only kept for the staged calls
+static int ensure_dense(jpg_ctx *c) {
+    const size_t need = worst_bits_bytes((size_t)c->g.nblocks);
+    if (c->eb.bits && c->eb.bits_cap >= need) return JPG_OK;
+    if (int e = regrow(c, c->eb.bits, need / 4)) return e;
+    c->eb.bits_cap = need;
     return JPG_OK;
 }
 
@@ -304,17 +315,14 @@ extern "C" int jpg_dct_quant(jpg_ctx *c) {
 
 static int queue_entropy(jpg_ctx *c, const int16_t pred[3]) {
     if (int e = ensure_entropy(c)) return e;
-    // a new generation of hand-off words per launch; clear them when the 14-bit counter wraps
-    if (c->eb.epoch == 0 || c->eb.epoch >= 16383) {
-        HIP_TRY(c, hipMemsetAsync(c->eb.agg, 0, c->hw_cap * sizeof(uint64_t), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->eb.grp, 0, (c->hw_cap / 64 + 1) * sizeof(uint64_t), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->eb.hyp, 0, (c->hw_cap / 4096 + 1) * sizeof(uint64_t), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->eb.tail, 0, c->hw_cap * sizeof(uint64_t), c->stream));
+    // errors are tagged with a launch number; clear the word before the number repeats
+    if (c->eb.epoch >= (1u << 22)) {
         HIP_TRY(c, hipMemsetAsync(c->eb.status, 0, sizeof(DevStatus), c->stream));
         c->eb.epoch = 0;
     }
     c->eb.epoch++;
     c->eb.host_status = c->h_status;
+    c->dense_valid = false;
     static const int16_t zero[3] = {0, 0, 0};   // src/jpeg/entropy_coding.rs:38-40
     HIP_TRY(c, launch_entropy(c->g, c->d_coef, pred ? pred : zero, c->eb, c->stream));
     return JPG_OK;
@@ -341,8 +349,13 @@ static int kernel_error(const jpg_ctx *c) {
     return JPG_OK;
 }
 
-static int fetch_status(jpg_ctx *c) {
-    HIP_TRY(c, hipMemcpyAsync(c->h_status, c->eb.status, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
+// gather the chunks into the dense stream (also reports nbits)
+static int make_dense(jpg_ctx *c) {
+    if (c->dense_valid) return JPG_OK;
+    if (int e = ensure_dense(c)) return e;
+    HIP_TRY(c, launch_dense(c->eb, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->dense_valid = true;
     return JPG_OK;
 }
 
@@ -351,8 +364,7 @@ static int entropy_common(jpg_ctx *c, const int16_t *pred, uint64_t *nbits) {
     if (c->stage < ST_COEF) return JPG_ERR_STATE;
     if (int e = use_device(c)) return e;
     if (int e = queue_entropy(c, pred)) return e;
-    if (int e = fetch_status(c)) return e;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int e = make_dense(c)) return e;
     if (int ke = kernel_error(c)) return ke;
     c->nbits = c->h_status->nbits;
     if (nbits) *nbits = c->nbits;
@@ -459,7 +471,9 @@ extern "C" void jpg_free(void *p) {
 }
 
 extern "C" const uint8_t *jpg_bits_device(jpg_ctx *c) {
-    return c && c->stage >= ST_BITS ? reinterpret_cast<const uint8_t *>(c->eb.bits) : nullptr;
+    if (!c || c->stage < ST_BITS || c->pending) return nullptr;
+    if (use_device(c) || make_dense(c)) return nullptr;
+    return reinterpret_cast<const uint8_t *>(c->eb.bits);
 }
 extern "C" const uint8_t *jpg_scan_device(jpg_ctx *c) { return c && c->stage >= ST_SCAN ? c->eb.scan : nullptr; }
 
@@ -469,6 +483,7 @@ extern "C" int jpg_get_bits(jpg_ctx *c, uint8_t *out, size_t cap) {
     const size_t n = (size_t)((c->nbits + 7) >> 3);
     if (cap < n) return JPG_ERR_CAPACITY;
     if (int e = use_device(c)) return e;
+    if (int e = make_dense(c)) return e;
     HIP_TRY(c, hipMemcpyAsync(out, c->eb.bits, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return JPG_OK;

@@ -9,17 +9,17 @@
 // consecutive blocks.  A thread walks only the non-zero coefficients of its
 // block (a 64-bit mask built while the block is read from LDS), so the work
 // follows the number of symbols, not the number of coefficients.  The wave
-//   1. measures its blocks, scans the lengths, announces the chunk's length,
-//   2. codes the blocks into LDS (bit 0 = first bit of the chunk),
-//   3. learns the chunk's bit offset in the stream from the lengths announced
-//      by the chunks before it (three levels of sums, so nobody waits on a chain),
-//   4. writes the bits to global memory shifted to that offset, as whole
-//      words: the word a chunk shares with its predecessor is written by the
-//      later chunk, which gets the predecessor's last 32 bits handed over.
-// A wave only ever waits for chunks with a lower number, which belong to
-// workgroups dispatched before its own.
+// measures its blocks, scans the lengths, codes the blocks into LDS (bit 0 =
+// first bit of the chunk) and stores the words to the chunk's own fixed-size
+// slot of the "sparse" buffer, together with the chunk's length in bits.  No
+// wave depends on another one.
 //
-// k_stuff then inserts 0x00 after every 0xFF, placing its segments the same way.
+// k_stream<true> (byte stuffing) and k_stream<false> (dense copy) read the
+// concatenation of the chunks: a workgroup sums the chunk lengths to find the
+// chunks under its 4 KiB segment of the stream and gathers the bits, shifted to
+// their place, straight from the chunk slots.  Stuffing then inserts 0x00 after
+// every 0xFF; the output offset of a segment comes from three levels of running
+// sums of the 0xFF counts, published by the segments before it.
 #include "../../include/jpeg_hip.h"
 #include "internal.hpp"
 #include "tables.h"
@@ -29,13 +29,16 @@ namespace jpg {
 __device__ const jpgtab::HuffLut HUFF_DEV{};
 constexpr int LUT_WORDS = 2 * jpgtab::HUFF_LUT_STRIDE;
 #ifndef JPG_ENT_THREADS
-#define JPG_ENT_THREADS 128
+#define JPG_ENT_THREADS 256
 #endif
 constexpr int ENT_THREADS = JPG_ENT_THREADS;
 constexpr int ENT_WAVES = ENT_THREADS / 64;
 constexpr uint32_t SPIN_LIMIT = 1u << 22;       // polls before a wave gives up waiting (never hang the GPU)
 constexpr int SLOT_BYTES = 144;                 // 128-byte block + 16: conflict-free 16-byte LDS access
-constexpr int OUT_WORDS = 1024;                 // LDS words a chunk's bits may take on the fast path (4 KiB)
+#ifndef JPG_ENT_OUT_WORDS
+#define JPG_ENT_OUT_WORDS 256
+#endif
+constexpr int OUT_WORDS = JPG_ENT_OUT_WORDS;    // LDS words of a chunk's bits coded per pass
 
 // inclusive prefix sum across the 64 lanes of a wavefront (DPP row shifts and broadcasts)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
@@ -53,9 +56,9 @@ struct EntArgs {
     long long nblocks, nchunks;
     int nb, hv;
     int16_t pred[3];
-    uint32_t epoch;
-    uint64_t *agg, *grp, *hyp, *tail;
-    uint32_t *bits;
+    uint32_t epoch;          // tags errors (see raise_error)
+    uint32_t *clen;          // [nchunks] out: bits of each chunk
+    uint32_t *sparse;        // [nchunks][CHUNK_STRIDE_WORDS] out: the chunk's bits, MSB first in each word
     DevStatus *status;
 };
 
@@ -258,13 +261,8 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy(EntArgs a) {
     for (int i = tid; i < LUT_WORDS; i += ENT_THREADS) sLut[i] = (&HUFF_DEV.e[0][0])[i];
 
     __syncthreads();
-    // A wave waits only for chunks with a lower number (see chunk_offset and the tail
-    // hand-off), i.e. for workgroups with a lower blockIdx.  Workgroups are dispatched in
-    // blockIdx order, so those are already running or finished; every wait is bounded all
-    // the same and ends in JPG_ERR_HIP rather than a hang.
     const long long chunk = (long long)blockIdx.x * ENT_WAVES + wave;
     if (chunk >= a.nchunks) return;                              // wave-uniform; no workgroup barrier follows
-    {
     const long long first = chunk * CHUNK_BLOCKS;
     const int nvalid = (int)min((long long)CHUNK_BLOCKS, a.nblocks - first);
 
@@ -305,110 +303,54 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy(EntArgs a) {
     const uint32_t len = valid ? code_block(slot, mlo, mhi, dc_diff, lut, a.status, a.epoch, nw) : 0u;
     const uint32_t sc = wave_incl_scan(len);                      // bits up to and including this lane's block
     const uint32_t total = __shfl(sc, 63);
-    const Sums sums{a.agg, a.grp, a.hyp, a.epoch, a.nchunks};
-    if (lane == 0) hw_store(&a.agg[chunk], hw_pack(a.epoch, total));
+    if (lane == 0) a.clen[chunk] = total;
 
-    // 2..4. code and write out; a chunk too long for the LDS window goes in several passes
+    // 2. code and store; a chunk too long for the LDS window goes in several passes, each
+    // starting in the word the previous one ended in (that word is carried over and stored again)
     uint32_t *out = sOut[wave];
+    uint32_t *dst = a.sparse + (size_t)chunk * CHUNK_STRIDE_WORDS;
     constexpr uint32_t WINDOW = OUT_WORDS * 32;                   // bits per pass
-    uint64_t O = 0;                                               // bit offset of the chunk, known after the first pass
-    uint32_t prev_tail = 0;                                       // the 32 stream bits before the current pass
-    uint32_t done = 0;                                            // bits of the chunk already written out
-    bool timeout = false;
+    uint32_t done = 0;                                            // bits of the chunk already stored
+    uint32_t carry = 0;                                           // the bits before `done` in its word
     for (int pass = 0; done < total || pass == 0; pass++) {
-        // lanes whose block ends within the window starting at `done` (at least one: a block is < WINDOW bits)
-        const bool mine = valid && sc > done && sc - done <= WINDOW;
+        const uint32_t start = done & 31;
+        // lanes whose block ends within the window (at least one: a block is shorter than WINDOW - 31 bits)
+        const bool mine = valid && sc > done && sc - done + start <= WINDOW;
         const uint32_t pass_bits = __shfl(mine ? sc - done : 0u, 63 - __clzll(__ballot(mine) | 1ull));
-        const uint32_t nw_local = (pass_bits + 31) >> 5;
-        for (uint32_t i = lane; i < nw_local + 1; i += 64) out[i] = 0;
+        const uint32_t nwords = (start + pass_bits + 31) >> 5;
+        for (uint32_t i = lane; i < nwords + 1; i += 64) out[i] = i ? 0u : carry;
         __builtin_amdgcn_wave_barrier();
         if (mine) {
             BitWriter w;
-            w.init(out, sc - len - done);
+            w.init(out, sc - len - done + start);
             code_block(slot, mlo, mhi, dc_diff, lut, a.status, a.epoch, w);
         }
         __builtin_amdgcn_wave_barrier();
-        const bool last_pass = done + pass_bits >= total;
-        // last 32 bits of the stream after this pass
-        uint32_t new_tail;
-        {
-            const uint32_t e = pass_bits;                         // > 0
-            const uint32_t wi = (e - 1) >> 5, r = e & 31;         // r = bits used in the last word (0 = full)
-            const uint32_t lastw = out[wi], beforew = wi ? out[wi - 1] : prev_tail;
-            new_tail = r ? __funnelshift_r(lastw, beforew, 32 - r) : lastw;
-            if (e < 32) new_tail = (prev_tail << e) | (out[0] >> (32 - e));
-        }
-        if (last_pass && lane == 0) hw_store(&a.tail[chunk], hw_pack(a.epoch, new_tail));
-        if (pass == 0) {
-            // 3. where does the chunk start?
-            // (looking at the predecessors' words any earlier only adds traffic: measured slower)
-            O = sums_prefix(sums, chunk, total, Probe{0, 0, 0}, lane, timeout);
-            if (chunk > 0) {
-                const uint64_t tail_word = hw_wait(&a.tail[chunk - 1], lane == 0, 0, a.epoch, timeout);
-                prev_tail = __shfl((uint32_t)tail_word, 0);
-            }
-            if (chunk == a.nchunks - 1 && lane == 0) a.status->nbits = O + total;
-            if (__ballot(timeout) && lane == 0) raise_error(a.status, a.epoch, JPG_ERR_HIP);
-        }
-        // 4. write the pass at bit O + done: word i = stream bits, preceded by prev_tail
-        const uint64_t P = O + done;
-        const uint32_t shift = (uint32_t)(P & 31);
-        const uint64_t W0 = P >> 5;
-        const uint32_t end_bits = shift + pass_bits;
-        // whole words only, except at the very end of the stream
-        const uint32_t nout = (last_pass && chunk == a.nchunks - 1) ? (end_bits + 31) >> 5 : end_bits >> 5;
-        for (uint32_t i = lane; i < nout; i += 64) {
-            const uint32_t hi = i ? out[i - 1] : prev_tail;
-            const uint32_t lo = i < nw_local ? out[i] : 0u;
-            a.bits[W0 + i] = __builtin_bswap32(shift ? __funnelshift_r(lo, hi, shift) : lo);
-        }
+        for (uint32_t i = lane; i < nwords; i += 64) dst[(done >> 5) + i] = out[i];
+        const uint32_t endb = start + pass_bits;
+        carry = (endb & 31) ? out[endb >> 5] : 0u;
         __builtin_amdgcn_wave_barrier();
-        prev_tail = new_tail;
         done += pass_bits;
-    }
     }
 }
 
-// ---------------------------------------------------------------- stuffing
+// ---------------------------------------------------------------- stream readers
 
-struct StuffArgs {
-    const uint32_t *in;      // unstuffed stream (whole words are defined up to the last one)
-    DevStatus *status;       // nbits in, scan_bytes and tail out
+struct StreamArgs {
+    const uint32_t *sparse;  // chunk slots written by k_entropy
+    const uint32_t *clen;    // bits per chunk
+    long long nchunks;
+    int ngroups;             // groups of 64 chunks (<= MAX_GROUPS)
+    DevStatus *status;       // nbits, scan_bytes and tail out
     uint32_t shift;          // place the stream `shift` (0..7) bits later
     uint32_t head;           // bits OR-ed into the first byte (top `shift` bits)
     int is_last;             // keep the trailing partial byte
     uint64_t *agg, *grp, *hyp;  // three-level sums of 0xFF counts per segment
     uint32_t epoch;          // generation of those words
     uint32_t err_epoch;      // epoch errors are tagged with (that of the entropy launch)
-    uint8_t *out;
+    uint8_t *out;            // stuffed bytes, or the dense stream for k_stream<false>
     DevStatus *host_status;  // pinned host copy, filled at the end (may be null)
 };
-
-__device__ __forceinline__ uint64_t shifted_bytes(const StuffArgs &a) {
-    const uint64_t tbits = a.status->nbits + a.shift;
-    return a.is_last ? (tbits + 7) >> 3 : tbits >> 3;
-}
-
-// 16 bytes of the shifted stream starting at byte 16*q, as 4 big-endian words
-__device__ __forceinline__ void load16(const StuffArgs &a, uint64_t q, uint64_t in_bytes, uint32_t (&t)[4]) {
-    uint32_t w[4];
-    const uint4 raw = 16 * q < in_bytes ? reinterpret_cast<const uint4 *>(a.in)[q] : make_uint4(0, 0, 0, 0);
-    w[0] = __builtin_bswap32(raw.x);
-    w[1] = 16 * q + 4 < in_bytes ? __builtin_bswap32(raw.y) : 0;
-    w[2] = 16 * q + 8 < in_bytes ? __builtin_bswap32(raw.z) : 0;
-    w[3] = 16 * q + 12 < in_bytes ? __builtin_bswap32(raw.w) : 0;
-    if (a.shift) {
-        uint32_t prev = 0;
-        if (q > 0 && 16 * q - 4 < in_bytes) prev = __builtin_bswap32(a.in[4 * q - 1]);
-        t[0] = __funnelshift_r(w[0], prev, a.shift);
-        t[1] = __funnelshift_r(w[1], w[0], a.shift);
-        t[2] = __funnelshift_r(w[2], w[1], a.shift);
-        t[3] = __funnelshift_r(w[3], w[2], a.shift);
-        if (q == 0) t[0] |= a.head << 24;
-    } else {
-        t[0] = w[0]; t[1] = w[1]; t[2] = w[2]; t[3] = w[3];
-    }
-}
 
 // number of 0xFF bytes in a word
 __device__ __forceinline__ uint32_t count_ff(uint32_t w) {
@@ -418,49 +360,211 @@ __device__ __forceinline__ uint32_t count_ff(uint32_t w) {
     return __popc(t);
 }
 
-// Byte stuffing in one pass: a workgroup takes segments of STUFF_SEG input bytes
-// (blockIdx.x, + gridDim.x, ...), counts their 0xFF bytes, learns how many precede the
-// segment from the three-level sums, and writes the segment with 0x00 after every 0xFF.
-__global__ __launch_bounds__(256) void k_stuff(StuffArgs a) {
+constexpr int SEG_BITS = STUFF_SEG * 8;
+constexpr int TABLE = 256;   // chunks whose offsets a workgroup tabulates per segment
+constexpr int SEG_WORDS = SEG_BITS / 32;
+constexpr int DENSE_WORDS = SEG_WORDS + 2;   // the segment, plus the byte after it (tail of a stripe)
+// words a segment can need from the chunk slots: its own, plus a partial one at either end of each
+// of the at most 130 chunks under it (a full chunk has at least 64 x 4 bits)
+constexpr int GATHER_ROUNDS = (DENSE_WORDS + 2 * 132 + 255) / 256;
+
+// index of the last entry <= r in the ascending table T[0..TABLE], or -1 if there is none
+__device__ __forceinline__ int find_last_le(const int *T, int r) {
+    int lo = -1, hi = TABLE;             // answer in [lo, hi]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (T[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// STUFF: byte stuffing of the (shifted) stream into a.out, a workgroup per segment of
+// STUFF_SEG stream bytes (blockIdx.x, + gridDim.x, ...).  !STUFF: the stream itself, dense.
+// Dynamic LDS: (ngroups + 1) 64-bit prefix sums of the chunk lengths per group.
+template <bool STUFF>
+__global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
+    extern __shared__ uint64_t sG[];     // [ngroups + 1] bits before each group of 64 chunks
+    __shared__ uint64_t sPart[256];
+    __shared__ int sT[TABLE + 1];          // chunk offsets relative to the segment's first bit
+    __shared__ int sW[TABLE + 1];          // running count of the words wanted from each chunk
+    __shared__ int sW0[TABLE];             // first word wanted from each chunk
+    __shared__ uint32_t sD[DENSE_WORDS];   // the segment's bits in place
     __shared__ uint32_t s[4];
     __shared__ uint64_t sBefore;
-    const uint64_t in_bytes = (a.status->nbits + 7) >> 3;
-    const uint64_t nbytes = shifted_bytes(a);
-    const uint64_t nseg = (nbytes + STUFF_SEG - 1) / STUFF_SEG;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const Sums sums{a.agg, a.grp, a.hyp, a.epoch, (long long)nseg};
-    if (nseg == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
-        a.status->scan_bytes = 0;
-        a.status->tail = 0;
-        if (a.host_status) *a.host_status = *a.status;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- bits per group, then their running sums
+    for (int g = tid; g < a.ngroups; g += 256) {
+        const long long c0 = (long long)g * 64;
+        uint32_t sum = 0;
+        if (c0 + 64 <= a.nchunks) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.clen + c0);
+            uint4 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = p[k];
+#pragma unroll
+            for (int k = 0; k < 16; k++) sum += v[k].x + v[k].y + v[k].z + v[k].w;
+        } else {
+            for (long long c = c0; c < a.nchunks; c++) sum += a.clen[c];
+        }
+        sG[g] = sum;
     }
-    for (uint64_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        const uint64_t q = seg * (STUFF_SEG / 16) + threadIdx.x;
-        uint32_t t[4];
-        load16(a, q, in_bytes, t);
-        uint32_t c = 0;
-        if (16 * q < nbytes) c = count_ff(t[0]) + count_ff(t[1]) + count_ff(t[2]) + count_ff(t[3]);
+    __syncthreads();
+    const int per = (a.ngroups + 255) / 256;
+    const int lo = min(tid * per, a.ngroups), hi = min(lo + per, a.ngroups);
+    uint64_t loc = 0;
+    for (int g = lo; g < hi; g++) loc += sG[g];
+    sPart[tid] = loc;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint64_t v = tid >= d ? sPart[tid - d] : 0;
+        __syncthreads();
+        sPart[tid] += v;
+        __syncthreads();
+    }
+    uint64_t run = sPart[tid] - loc;
+    for (int g = lo; g < hi; g++) {
+        const uint64_t v = sG[g];
+        sG[g] = run;
+        run += v;
+    }
+    const uint64_t nbits = sPart[255];
+    if (tid == 0) sG[a.ngroups] = nbits;
+    __syncthreads();
+
+    const uint64_t tbits = nbits + a.shift;
+    const uint64_t nbytes = (STUFF && !a.is_last) ? tbits >> 3 : (tbits + 7) >> 3;
+    const uint64_t nseg = (nbytes + STUFF_SEG - 1) / STUFF_SEG;
+    const uint64_t nloop = nseg ? nseg : 1;          // the tail of an empty stripe still has to be reported
+    const Sums sums{a.agg, a.grp, a.hyp, a.epoch, (long long)nseg};
+
+    for (uint64_t seg = blockIdx.x; seg < nloop; seg += gridDim.x) {
+        // ---- offsets of the chunks under this segment
+        const long long P0 = (long long)seg * SEG_BITS - (long long)a.shift;   // stream position of the segment's first bit
+        const uint64_t p0 = P0 > 0 ? (uint64_t)P0 : 0;
+        int g0 = 0;
+        {
+            int l = 0, h = a.ngroups - 1;
+            while (l < h) {
+                const int mid = (l + h + 1) >> 1;
+                if (sG[mid] <= p0) l = mid; else h = mid - 1;
+            }
+            g0 = l;
+        }
+        const long long cbase = (long long)g0 * 64;
+        const uint32_t v = cbase + tid < a.nchunks ? a.clen[cbase + tid] : 0u;
+        const uint32_t vs = wave_incl_scan(v);
+        if (lane == 63) s[wave] = vs;
+        __syncthreads();
+        uint32_t ex = vs - v;
+        for (int w = 0; w < wave; w++) ex += s[w];
+        const long long rel0 = (long long)sG[g0] - P0;
+        sT[tid] = (int)(rel0 + ex);
+        if (tid == 255) sT[256] = (int)(rel0 + ex + v);
+        __syncthreads();
+
+        // ---- gather: every word of a chunk slot that overlaps the segment is OR-ed into place
+        const uint32_t *slots = a.sparse + (size_t)cbase * CHUNK_STRIDE_WORDS;
+        {
+            const int Ti = sT[tid], L = sT[tid + 1] - Ti;
+            const int b0 = max(0, -Ti), b1 = min(L, DENSE_WORDS * 32 - Ti);   // bits of the chunk inside the window
+            const int w0 = b0 >> 5, n = b1 > b0 ? ((b1 + 31) >> 5) - w0 : 0;
+            sW0[tid] = w0;
+            __syncthreads();                                       // s[] is reused
+            const uint32_t ns = wave_incl_scan((uint32_t)n);
+            if (lane == 63) s[wave] = ns;
+            __syncthreads();
+            uint32_t nex = ns - n;
+            for (int w = 0; w < wave; w++) nex += s[w];
+            sW[tid] = (int)nex;
+            if (tid == 255) sW[256] = (int)(nex + n);
+        }
+        for (int k = tid; k < DENSE_WORDS; k += 256) sD[k] = 0;
+        __syncthreads();
+        {
+            const int nwant = sW[256];
+            uint32_t wv[GATHER_ROUNDS];
+            int pos[GATHER_ROUNDS];
+#pragma unroll
+            for (int m = 0; m < GATHER_ROUNDS; m++) {
+                const int f = tid + 256 * m;
+                wv[m] = 0;
+                pos[m] = 0;
+                if (f < nwant) {
+                    const int i = find_last_le(sW, f);            // the last of equal entries is the non-empty one
+                    const int j = sW0[i] + (f - sW[i]);
+                    wv[m] = slots[(size_t)i * CHUNK_STRIDE_WORDS + j];
+                    pos[m] = sT[i] + 32 * j;                      // where the word's first bit goes (>= -31)
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < GATHER_ROUNDS; m++) {
+                if (wv[m]) {
+                    const int k = pos[m] >> 5, sh = pos[m] & 31;
+                    if (k >= 0 && k < DENSE_WORDS) atomicOr(&sD[k], wv[m] >> sh);
+                    if (sh && k + 1 >= 0 && k + 1 < DENSE_WORDS) atomicOr(&sD[k + 1], wv[m] << (32 - sh));
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- this thread's 16 bytes
+        const uint64_t q = seg * (STUFF_SEG / 16) + tid;
+        uint32_t t[4] = {0, 0, 0, 0};
+        if (16 * q < nbytes) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[k] = sD[4 * tid + k];
+            if (q == 0 && a.shift) t[0] |= a.head << 24;
+            // a stripe that is not the last one ends at a byte boundary: drop what follows
+            const uint64_t rem = nbytes - 16 * q;
+            if (rem < 16) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const long long keep = (long long)rem - 4 * k;   // bytes of word k inside the stream
+                    if (keep <= 0) t[k] = 0;
+                    else if (keep < 4) t[k] &= ~0u << (32 - 8 * (int)keep);
+                }
+            }
+        }
+        if (!STUFF) {
+            if (16 * q < nbytes) {
+                uint4 o = make_uint4(__builtin_bswap32(t[0]), __builtin_bswap32(t[1]), __builtin_bswap32(t[2]),
+                                     __builtin_bswap32(t[3]));
+                reinterpret_cast<uint4 *>(a.out)[q] = o;           // the buffer is padded to 16 bytes
+            }
+            if (seg == nloop - 1 && tid == 0) {
+                a.status->nbits = nbits;
+                if (a.host_status) *a.host_status = *a.status;
+            }
+            __syncthreads();
+            continue;
+        }
+        const uint32_t c = count_ff(t[0]) + count_ff(t[1]) + count_ff(t[2]) + count_ff(t[3]);
+        __syncthreads();                                           // s[] is reused
         const uint32_t sc = wave_incl_scan(c);
         if (lane == 63) s[wave] = sc;
         __syncthreads();
         const uint32_t total = s[0] + s[1] + s[2] + s[3];
         if (wave == 0) {
             bool timeout = false;
-            if (lane == 0) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
-            const Probe probe = sums_probe(sums, (long long)seg, lane);
-            const uint64_t before = sums_prefix(sums, (long long)seg, total, probe, lane, timeout);
+            uint64_t before = 0;
+            if (nseg) {
+                if (lane == 0) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
+                const Probe probe = sums_probe(sums, (long long)seg, lane);
+                before = sums_prefix(sums, (long long)seg, total, probe, lane, timeout);
+            }
             if (lane == 0) {
                 sBefore = before;
                 if (timeout) raise_error(a.status, a.err_epoch, JPG_ERR_HIP);
-                if (seg == nseg - 1) {
+                if (seg == nloop - 1) {
+                    a.status->nbits = nbits;
                     a.status->scan_bytes = nbytes + before + total;
                     // bits of the partial byte a non-final stripe leaves to its successor
-                    const uint64_t tbits = a.status->nbits + a.shift;
                     uint32_t tail = 0;
                     if (!a.is_last && (tbits & 7)) {
-                        uint32_t u[4];
-                        load16(a, nbytes >> 4, in_bytes, u);
-                        tail = (u[(nbytes >> 2) & 3] >> (24 - 8 * (nbytes & 3))) & 0xffu;
+                        const int r = (int)(8 * nbytes - seg * SEG_BITS);
+                        tail = (sD[r >> 5] >> (24 - (r & 31))) & 0xffu;
+                        if (nbytes == 0) tail |= a.head;
                     }
                     a.status->tail = tail;
                     if (a.host_status) *a.host_status = *a.status;
@@ -470,17 +574,17 @@ __global__ __launch_bounds__(256) void k_stuff(StuffArgs a) {
         __syncthreads();
         uint32_t before = sc - c;
         for (int w = 0; w < wave; w++) before += s[w];
-        uint8_t *o = a.out + seg * STUFF_SEG + sBefore + 16 * threadIdx.x + before;
+        uint8_t *o = a.out + seg * STUFF_SEG + sBefore + 16 * tid + before;
         if (16 * q + 16 <= nbytes && c == 0 && ((reinterpret_cast<uintptr_t>(o) & 3) == 0)) {
             // common case: 16 plain bytes, destination word-aligned
             uint32_t *o4 = reinterpret_cast<uint32_t *>(o);
 #pragma unroll
-            for (int i = 0; i < 4; i++) o4[i] = __builtin_bswap32(t[i]);
+            for (int k = 0; k < 4; k++) o4[k] = __builtin_bswap32(t[k]);
         } else {
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                if (16 * q + i < nbytes) {
-                    const uint8_t b = (uint8_t)(t[i >> 2] >> (24 - 8 * (i & 3)));
+            for (int k = 0; k < 16; k++) {
+                if (16 * q + k < nbytes) {
+                    const uint8_t b = (uint8_t)(t[k >> 2] >> (24 - 8 * (k & 3)));
                     *o++ = b;
                     if (b == 0xff) *o++ = 0;
                 }
@@ -494,18 +598,31 @@ hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred
                           hipStream_t s) {
     const long long nchunks = (g.nblocks + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
     const unsigned grid = (unsigned)((nchunks + ENT_WAVES - 1) / ENT_WAVES);
-    EntArgs a{coef, g.nblocks, nchunks, g.nb, g.h * g.v, {pred[0], pred[1], pred[2]}, b.epoch, b.agg, b.grp, b.hyp, b.tail,
-              b.bits, b.status};
+    EntArgs a{coef, g.nblocks, nchunks, g.nb, g.h * g.v, {pred[0], pred[1], pred[2]}, b.epoch, b.clen, b.sparse, b.status};
     hipLaunchKernelGGL(k_entropy, dim3(grid), dim3(ENT_THREADS), 0, s, a);
     return hipGetLastError();
 }
 
+static StreamArgs stream_args(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, uint8_t *out) {
+    return StreamArgs{b.sparse, b.clen, b.nchunks, (int)((b.nchunks + 63) / 64), b.status, (uint32_t)(bit_offset & 7),
+                      head_bits, is_last, b.sagg, b.sgrp, b.shyp, b.stuff_epoch, b.epoch, out, b.host_status};
+}
+
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s) {
-    StuffArgs a{b.bits, b.status, (uint32_t)(bit_offset & 7), head_bits, is_last, b.sagg, b.sgrp, b.shyp, b.stuff_epoch,
-                b.epoch, b.scan, b.host_status};
+    const StreamArgs a = stream_args(b, bit_offset, head_bits, is_last, b.scan);
+    if (a.ngroups > MAX_GROUPS) return hipErrorInvalidValue;
     const size_t cap = b.stuff_grid ? b.stuff_grid : 1024;
     const unsigned grid = (unsigned)(b.nseg_cap < cap ? (b.nseg_cap ? b.nseg_cap : 1) : cap);
-    hipLaunchKernelGGL(k_stuff, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_stream<true>, dim3(grid), dim3(256), (a.ngroups + 1) * sizeof(uint64_t), s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_dense(const EntropyBufs &b, hipStream_t s) {
+    const StreamArgs a = stream_args(b, 0, 0, 1, reinterpret_cast<uint8_t *>(b.bits));
+    if (a.ngroups > MAX_GROUPS || !b.bits) return hipErrorInvalidValue;
+    const size_t cap = b.stuff_grid ? b.stuff_grid : 1024;
+    const unsigned grid = (unsigned)(b.nseg_cap < cap ? (b.nseg_cap ? b.nseg_cap : 1) : cap);
+    hipLaunchKernelGGL(k_stream<false>, dim3(grid), dim3(256), (a.ngroups + 1) * sizeof(uint64_t), s, a);
     return hipGetLastError();
 }
 

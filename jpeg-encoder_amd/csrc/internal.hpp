@@ -34,8 +34,13 @@ enum { ALGO_REAL = 0, ALGO_BIN = 1, ALGO_REAL_STRICT = 2 };
 constexpr int CHUNK_BLOCKS = 64;
 // worst-case coded size of one block: DC 9+11 bits, 63 AC x (16+10) bits
 constexpr int MAX_BLOCK_BITS = 20 + 63 * 26;
+// words of a chunk's slot in the sparse buffer: room for 64 blocks of maximum size
+constexpr int CHUNK_STRIDE_WORDS = 3328;
+static_assert(CHUNK_STRIDE_WORDS * 32 >= CHUNK_BLOCKS * MAX_BLOCK_BITS + 64, "chunk slot too small");
 // byte-stuffing works on segments of this many unstuffed bytes
 constexpr int STUFF_SEG = 4096;
+// groups of 64 chunks a stream reader can tabulate in LDS (limits an image to 16.7M blocks)
+constexpr int MAX_GROUPS = 4096;
 
 // results a host needs after an encode, fetched with one copy
 struct DevStatus {
@@ -46,20 +51,21 @@ struct DevStatus {
 };
 
 struct EntropyBufs {
-    // per-chunk hand-off words of the single-pass scan (see entropy.hip); each is
-    // {epoch:14 | valid:1 | value:49} written by one 8-byte store
-    uint64_t *agg;         // [nchunks] bits of the chunk
-    uint64_t *grp;         // [nchunks/64] bits of a group of 64 chunks
-    uint64_t *hyp;         // [nchunks/4096] bits of a hyper-group of 64 groups
-    uint64_t *tail;        // [nchunks] last 32 bits of the chunk
-    uint32_t epoch;        // generation of the words above (host side, 1..16383)
+    long long nchunks;     // chunks of the current image
+    uint32_t *clen;        // [nchunks] bits of each chunk
+    uint32_t *sparse;      // [nchunks][CHUNK_STRIDE_WORDS] coded bits of each chunk, MSB first in each word
+    uint32_t epoch;        // tags the error word of the current entropy launch (host side, 1..2^22)
     DevStatus *status;
     DevStatus *host_status;  // pinned host copy the last kernel fills (may be null)
-    uint32_t *bits;        // unstuffed MSB-first stream, as 32-bit words in memory byte order
+    uint32_t *bits;        // dense unstuffed MSB-first stream in memory byte order (staged API only, may be null)
     size_t bits_cap;       // bytes
-    uint64_t *sagg, *sgrp, *shyp;  // the same three levels for the 0xFF counts of the stuffing segments
+    // running sums of the 0xFF counts of the stuffing segments (see entropy.hip); each word is
+    // {epoch:14 | valid:1 | value:49} written by one 8-byte store
+    uint64_t *sagg;        // [nseg] 0xFF bytes of the segment
+    uint64_t *sgrp;        // [nseg/64] ... of a group of 64 segments
+    uint64_t *shyp;        // [nseg/4096] ... of a hyper-group of 64 groups
     uint32_t stuff_epoch;  // their generation (1..16383)
-    size_t stuff_grid;     // workgroups of the stuffing kernel (all must be able to be resident)
+    size_t stuff_grid;     // workgroups of the stream kernels (all must be able to be resident)
     uint8_t *scan;         // stuffed stream
     size_t scan_cap;
     size_t nseg_cap;
@@ -78,5 +84,7 @@ hipError_t launch_last_dc(const Geom &g, const int16_t *coef, int16_t *dc3, hipS
 hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred[3], const EntropyBufs &b,
                           hipStream_t s);
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s);
+// writes the dense stream to b.bits
+hipError_t launch_dense(const EntropyBufs &b, hipStream_t s);
 
 }  // namespace jpg
