@@ -36,7 +36,7 @@ constexpr int ENT_WAVES = ENT_THREADS / 64;
 constexpr uint32_t SPIN_LIMIT = 1u << 22;       // polls before a wave gives up waiting (never hang the GPU)
 constexpr int SLOT_BYTES = 144;                 // 128-byte block + 16: conflict-free 16-byte LDS access
 #ifndef JPG_ENT_OUT_WORDS
-#define JPG_ENT_OUT_WORDS 256
+#define JPG_ENT_OUT_WORDS 64
 #endif
 constexpr int OUT_WORDS = JPG_ENT_OUT_WORDS;    // LDS words of a chunk's bits coded per pass
 
@@ -105,10 +105,39 @@ struct BitWriter {
     }
 };
 
-struct NullWriter {
-    __device__ __forceinline__ void put(uint32_t, uint32_t) {}
+// Collects the last 128 bits put; a block of at most 128 bits is then complete in registers.
+struct AccWriter {
+    uint64_t hi = 0, lo = 0;
+    // 2 <= len <= 26
+    __device__ __forceinline__ void put(uint32_t value, uint32_t len) {
+        hi = (hi << len) | (lo >> (64 - len));
+        lo = (lo << len) | value;
+    }
     __device__ __forceinline__ void finish() {}
+    // ORs the n collected bits (1 <= n <= 128) into `out` starting at bit `pos`
+    __device__ __forceinline__ void emit(uint32_t *out, uint32_t pos, uint32_t n) const {
+        uint64_t H, L;
+        if (n <= 64) {
+            H = lo << (64 - n);
+            L = 0;
+        } else {
+            const uint32_t s = 128 - n;                          // 0..63
+            H = (hi << s) | (s ? lo >> (64 - s) : 0);
+            L = lo << s;
+        }
+        const uint32_t w0 = (uint32_t)(H >> 32), w1 = (uint32_t)H, w2 = (uint32_t)(L >> 32), w3 = (uint32_t)L;
+        const uint32_t sh = pos & 31;
+        uint32_t *o = out + (pos >> 5);
+        const uint32_t x0 = w0 >> sh, x1 = __funnelshift_r(w1, w0, sh), x2 = __funnelshift_r(w2, w1, sh),
+                       x3 = __funnelshift_r(w3, w2, sh), x4 = __funnelshift_r(0u, w3, sh);
+        atomicOr(&o[0], x0);
+        if (x1) atomicOr(&o[1], x1);
+        if (x2) atomicOr(&o[2], x2);
+        if (x3) atomicOr(&o[3], x3);
+        if (x4) atomicOr(&o[4], x4);
+    }
 };
+constexpr uint32_t ACC_BITS = 128;
 
 // Codes one block held in LDS at `slot` (64 int16, zigzag order).  mask: bit k
 // set where coefficient k is non-zero (k >= 1).  Returns the coded length.
@@ -129,31 +158,33 @@ __device__ __forceinline__ uint32_t code_block(const uint16_t *slot, uint32_t ml
     w.put(((t & 0xffff) << size) | amp, (t >> 16) + size);
     const uint32_t zrl = lut[0xf0];
     int prevk = 0;
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        uint32_t m = half ? mhi : mlo;
-        while (m) {
-            const int k = 32 * half + (__ffs(m) - 1);
-            m &= m - 1;
-            const int v = (int16_t)slot[k];
-            uint32_t run = (uint32_t)(k - prevk - 1);
-            prevk = k;
-            while (run >= 16) {                                  // ZRL per 16 zeros (src/jpeg/entropy_coding.rs:179-185)
-                w.put(zrl & 0xffff, zrl >> 16);
-                bits += zrl >> 16;
-                run -= 16;
-            }
-            mag = (uint32_t)(v < 0 ? -v : v);
-            size = 32 - __clz(mag);
-            if (size > 10) {
-                raise_error(st, epoch, JPG_ERR_AC_RANGE);
-                size = 0;
-            }
-            amp = (uint32_t)(v < 0 ? v - 1 : v) & ((1u << size) - 1u);
-            t = lut[(run << 4) | size];
-            bits += (t >> 16) + size;
-            w.put(((t & 0xffff) << size) | amp, (t >> 16) + size);
+    uint64_t m = ((uint64_t)mhi << 32) | mlo;
+    // the coefficient of the next symbol is read while the current one is coded
+    int k = m ? __ffsll((unsigned long long)m) - 1 : 0;
+    int v = (int16_t)slot[k];
+    while (m) {
+        m &= m - 1;
+        const int kn = m ? __ffsll((unsigned long long)m) - 1 : 0;
+        const int vn = (int16_t)slot[kn];
+        uint32_t run = (uint32_t)(k - prevk - 1);
+        prevk = k;
+        while (run >= 16) {                                      // ZRL per 16 zeros (src/jpeg/entropy_coding.rs:179-185)
+            w.put(zrl & 0xffff, zrl >> 16);
+            bits += zrl >> 16;
+            run -= 16;
         }
+        mag = (uint32_t)(v < 0 ? -v : v);
+        size = 32 - __clz(mag);
+        if (size > 10) {
+            raise_error(st, epoch, JPG_ERR_AC_RANGE);
+            size = 0;
+        }
+        amp = (uint32_t)(v < 0 ? v - 1 : v) & ((1u << size) - 1u);
+        t = lut[(run << 4) | size];
+        bits += (t >> 16) + size;
+        w.put(((t & 0xffff) << size) | amp, (t >> 16) + size);
+        k = kn;
+        v = vn;
     }
     if (prevk != 63) {                                           // trailing zeros -> EOB (src/jpeg/entropy_coding.rs:171-177)
         t = lut[0x00];
@@ -252,85 +283,150 @@ __device__ __forceinline__ uint64_t sums_prefix(const Sums &s, long long i, uint
     return wave_sum64(sh) + sum_g + sum_a;
 }
 
-__global__ __launch_bounds__(ENT_THREADS) void k_entropy(EntArgs a) {
+// block `jb` of its MCU (0..nb-1): the block before it in the same component's DC chain,
+// relative to the block itself (src/jpeg/entropy_coding.rs:74-124)
+__device__ __forceinline__ int prev_distance(int jb, int nb, int hv) {
+    return jb >= hv ? nb : (jb > 0 ? 1 : nb - hv + 1);
+}
+
+__device__ __forceinline__ uint32_t mod_small(uint32_t x, uint32_t nb, uint32_t magic) {   // x < 1024
+    return x - nb * ((x * magic) >> 16);
+}
+
+// Loads of one chunk, issued one chunk ahead: the 8 KiB of coefficients (8 coalesced 16-byte
+// pieces per lane) into R0..R7 and, for the few blocks whose DC predecessor lies before the chunk,
+// that DC into PDC.  Branch-free (addresses are clamped instead) so that the loads can stay in
+// flight across the coding of the previous chunk.
+#define JPG_CHUNK_LOAD(CH, FM, R, PDC)                                                              \
+    do {                                                                                            \
+        const long long first_ = (CH) * CHUNK_BLOCKS;                                               \
+        const uint4 *src_ = reinterpret_cast<const uint4 *>(a.coef);                                \
+        R##0 = src_[min(first_ * 8 + 0 * 64 + lane, last_piece)];                                   \
+        R##1 = src_[min(first_ * 8 + 1 * 64 + lane, last_piece)];                                   \
+        R##2 = src_[min(first_ * 8 + 2 * 64 + lane, last_piece)];                                   \
+        R##3 = src_[min(first_ * 8 + 3 * 64 + lane, last_piece)];                                   \
+        R##4 = src_[min(first_ * 8 + 4 * 64 + lane, last_piece)];                                   \
+        R##5 = src_[min(first_ * 8 + 5 * 64 + lane, last_piece)];                                   \
+        R##6 = src_[min(first_ * 8 + 6 * 64 + lane, last_piece)];                                   \
+        R##7 = src_[min(first_ * 8 + 7 * 64 + lane, last_piece)];                                   \
+        const int jb_ = (int)mod_small((FM) + lane, a.nb, magic);                                   \
+        const long long prev_ = first_ + lane - prev_distance(jb_, a.nb, a.hv);                     \
+        /* lanes that need nothing from outside read the chunk's first line, loaded anyway */       \
+        PDC = a.coef[((prev_ >= 0 && prev_ < first_) ? prev_ : min(first_, a.nblocks - 1)) * 64];   \
+    } while (0)
+
+// Persistent: a wave takes chunks blockIdx.x * ENT_WAVES + wave, + gridDim.x * ENT_WAVES, ...
+// (LDS limits a SIMD to 3 waves, so the register budget may be spent on keeping the prefetch in registers)
+__global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_entropy(EntArgs a) {
     __shared__ uint32_t sLut[LUT_WORDS];
     __shared__ __attribute__((aligned(16))) uint8_t sCoef[ENT_WAVES][CHUNK_BLOCKS * SLOT_BYTES];
     __shared__ uint32_t sOut[ENT_WAVES][OUT_WORDS + 2];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long stride = (long long)gridDim.x * ENT_WAVES;
+    long long chunk = (long long)blockIdx.x * ENT_WAVES + wave;
+    const uint32_t magic = (65536u + a.nb - 1) / a.nb;            // x / nb == (x * magic) >> 16 for small x
+    uint32_t fm = (uint32_t)((chunk * CHUNK_BLOCKS) % a.nb);      // first block of the chunk within its MCU
+    const uint32_t fm_step = (uint32_t)((stride * CHUNK_BLOCKS) % a.nb);
+    const long long last_piece = a.nblocks * 8 - 1;
+    uint4 pre0, pre1, pre2, pre3, pre4, pre5, pre6, pre7;   // (an array would be kept in scratch memory)
+    int pre_pdc;
+    JPG_CHUNK_LOAD(min(chunk, a.nchunks - 1), fm, pre, pre_pdc);
+
     for (int i = tid; i < LUT_WORDS; i += ENT_THREADS) sLut[i] = (&HUFF_DEV.e[0][0])[i];
-
     __syncthreads();
-    const long long chunk = (long long)blockIdx.x * ENT_WAVES + wave;
-    if (chunk >= a.nchunks) return;                              // wave-uniform; no workgroup barrier follows
-    const long long first = chunk * CHUNK_BLOCKS;
-    const int nvalid = (int)min((long long)CHUNK_BLOCKS, a.nblocks - first);
 
-    // stage the chunk's coefficients: coalesced 16-byte loads, one padded slot per block
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.coef) + first * 8;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int u = i * 64 + lane;                              // 16-byte piece inside the chunk
-        if ((u >> 3) < nvalid)
-            *reinterpret_cast<uint4 *>(&sCoef[wave][(u >> 3) * SLOT_BYTES + (u & 7) * 16]) = src[u];
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    const long long blk = first + lane;
-    const bool valid = lane < nvalid;
-    const uint16_t *slot = reinterpret_cast<const uint16_t *>(&sCoef[wave][lane * SLOT_BYTES]);
-    uint32_t mlo = 0, mhi = 0;
-    int dc_diff = 0;
-    uint32_t chroma = 0;
-    if (valid) {
-        uint4 q[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) q[i] = reinterpret_cast<const uint4 *>(slot)[i];
-        nonzero_mask(q, mlo, mhi);
-        mlo &= ~1u;                                               // the DC symbol is coded separately
-        // DC difference against the previous block of the same component
-        // (three predictor chains, src/jpeg/entropy_coding.rs:38-40,149-150)
-        const int jb = (int)(blk % a.nb);
-        chroma = jb >= a.hv ? 1u : 0u;
-        const long long prev = chroma ? blk - a.nb : (jb > 0 ? blk - 1 : blk - a.nb + a.hv - 1);
-        const int pdc = prev >= 0 ? (int)a.coef[prev * 64] : (int)a.pred[chroma ? jb - a.hv + 1 : 0];
-        dc_diff = (int16_t)((int)(int16_t)(q[0].x & 0xffff) - pdc);
-    }
-    const uint32_t *lut = sLut + chroma * jpgtab::HUFF_LUT_STRIDE;
-
-    // 1. lengths
-    NullWriter nw;
-    const uint32_t len = valid ? code_block(slot, mlo, mhi, dc_diff, lut, a.status, a.epoch, nw) : 0u;
-    const uint32_t sc = wave_incl_scan(len);                      // bits up to and including this lane's block
-    const uint32_t total = __shfl(sc, 63);
-    if (lane == 0) a.clen[chunk] = total;
-
-    // 2. code and store; a chunk too long for the LDS window goes in several passes, each
-    // starting in the word the previous one ended in (that word is carried over and stored again)
+    uint8_t *coefs = sCoef[wave];
     uint32_t *out = sOut[wave];
-    uint32_t *dst = a.sparse + (size_t)chunk * CHUNK_STRIDE_WORDS;
-    constexpr uint32_t WINDOW = OUT_WORDS * 32;                   // bits per pass
-    uint32_t done = 0;                                            // bits of the chunk already stored
-    uint32_t carry = 0;                                           // the bits before `done` in its word
-    for (int pass = 0; done < total || pass == 0; pass++) {
-        const uint32_t start = done & 31;
-        // lanes whose block ends within the window (at least one: a block is shorter than WINDOW - 31 bits)
-        const bool mine = valid && sc > done && sc - done + start <= WINDOW;
-        const uint32_t pass_bits = __shfl(mine ? sc - done : 0u, 63 - __clzll(__ballot(mine) | 1ull));
-        const uint32_t nwords = (start + pass_bits + 31) >> 5;
-        for (uint32_t i = lane; i < nwords + 1; i += 64) out[i] = i ? 0u : carry;
-        __builtin_amdgcn_wave_barrier();
-        if (mine) {
-            BitWriter w;
-            w.init(out, sc - len - done + start);
-            code_block(slot, mlo, mhi, dc_diff, lut, a.status, a.epoch, w);
+    const uint16_t *slot = reinterpret_cast<const uint16_t *>(&coefs[lane * SLOT_BYTES]);
+    for (; chunk < a.nchunks; chunk += stride) {
+        const long long first = chunk * CHUNK_BLOCKS;
+        const int nvalid = (int)min((long long)CHUNK_BLOCKS, a.nblocks - first);
+
+        // stage the chunk's coefficients, one padded slot per block
+        {
+            // 16-byte piece i * 64 + lane of the chunk goes to block (piece >> 3), offset (piece & 7) * 16
+            uint8_t *d = &coefs[(lane >> 3) * SLOT_BYTES + (lane & 7) * 16];
+            constexpr int STEP = 8 * SLOT_BYTES;
+            *reinterpret_cast<uint4 *>(d + 0 * STEP) = pre0;
+            *reinterpret_cast<uint4 *>(d + 1 * STEP) = pre1;
+            *reinterpret_cast<uint4 *>(d + 2 * STEP) = pre2;
+            *reinterpret_cast<uint4 *>(d + 3 * STEP) = pre3;
+            *reinterpret_cast<uint4 *>(d + 4 * STEP) = pre4;
+            *reinterpret_cast<uint4 *>(d + 5 * STEP) = pre5;
+            *reinterpret_cast<uint4 *>(d + 6 * STEP) = pre6;
+            *reinterpret_cast<uint4 *>(d + 7 * STEP) = pre7;
         }
+        const int pdc_outside = pre_pdc;
+        const uint32_t fm_now = fm;
+        // the next chunk's loads fly while this one is coded
+        fm = mod_small(fm + fm_step, a.nb, magic);
+        JPG_CHUNK_LOAD(min(chunk + stride, a.nchunks - 1), fm, pre, pre_pdc);
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t i = lane; i < nwords; i += 64) dst[(done >> 5) + i] = out[i];
-        const uint32_t endb = start + pass_bits;
-        carry = (endb & 31) ? out[endb >> 5] : 0u;
-        __builtin_amdgcn_wave_barrier();
-        done += pass_bits;
+
+        const bool valid = lane < nvalid;
+        uint32_t mlo = 0, mhi = 0;
+        int dc_diff = 0;
+        uint32_t chroma = 0;
+        {
+            uint4 q[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) q[i] = reinterpret_cast<const uint4 *>(slot)[i];
+            nonzero_mask(q, mlo, mhi);
+            mlo &= ~1u;                                           // the DC symbol is coded separately
+            // DC difference against the previous block of the same component
+            // (three predictor chains, src/jpeg/entropy_coding.rs:38-40,149-150)
+            const int jb = (int)mod_small(fm_now + lane, a.nb, magic);
+            chroma = jb >= a.hv ? 1u : 0u;
+            const int back = prev_distance(jb, a.nb, a.hv);
+            int pdc;
+            // (selects, not an indexed read of the argument block: that would be a memory load)
+            if (first + lane - back < 0) pdc = jb < a.hv ? a.pred[0] : (jb == a.hv ? a.pred[1] : a.pred[2]);
+            else if (lane < back) pdc = pdc_outside;
+            else pdc = (int16_t)reinterpret_cast<const uint16_t *>(&coefs[(lane - back) * SLOT_BYTES])[0];
+            dc_diff = (int16_t)((int)(int16_t)(q[0].x & 0xffff) - pdc);
+            if (!valid) { mlo = 0; mhi = 0; dc_diff = 0; }
+        }
+        const uint32_t *lut = sLut + chroma * jpgtab::HUFF_LUT_STRIDE;
+
+        // 1. lengths
+        AccWriter acc;                                            // blocks of up to ACC_BITS bits are kept whole
+        const uint32_t len = valid ? code_block(slot, mlo, mhi, dc_diff, lut, a.status, a.epoch, acc) : 0u;
+        const uint32_t sc = wave_incl_scan(len);                  // bits up to and including this lane's block
+        const uint32_t total = __shfl(sc, 63);
+        if (lane == 0) a.clen[chunk] = total;
+
+        // 2. code and store; a chunk too long for the LDS window goes in several passes, each
+        // starting in the word the previous one ended in (that word is carried over and stored again)
+        uint32_t *dst = a.sparse + (size_t)chunk * CHUNK_STRIDE_WORDS;
+        constexpr uint32_t WINDOW = OUT_WORDS * 32;               // bits per pass
+        uint32_t done = 0;                                        // bits of the chunk already stored
+        uint32_t carry = 0;                                       // the bits before `done` in its word
+        for (int pass = 0; done < total || pass == 0; pass++) {
+            const uint32_t start = done & 31;
+            // lanes whose block ends within the window (at least one: a block is shorter than WINDOW - 31 bits)
+            const bool mine = valid && sc > done && sc - done + start <= WINDOW;
+            const uint32_t pass_bits = __shfl(mine ? sc - done : 0u, 63 - __clzll(__ballot(mine) | 1ull));
+            const uint32_t nwords = (start + pass_bits + 31) >> 5;
+            for (uint32_t i = lane; i < nwords + 1; i += 64) out[i] = i ? 0u : carry;
+            __builtin_amdgcn_wave_barrier();
+            if (mine) {
+                const uint32_t pos = sc - len - done + start;
+                if (len <= ACC_BITS) {
+                    acc.emit(out, pos, len);
+                } else {                                          // long block: walk it again
+                    BitWriter w;
+                    w.init(out, pos);
+                    code_block(slot, mlo, mhi, dc_diff, lut, a.status, a.epoch, w);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < nwords; i += 64) dst[(done >> 5) + i] = out[i];
+            const uint32_t endb = start + pass_bits;
+            carry = (endb & 31) ? out[endb >> 5] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            done += pass_bits;
+        }
     }
 }
 
@@ -597,7 +693,21 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
 hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred[3], const EntropyBufs &b,
                           hipStream_t s) {
     const long long nchunks = (g.nblocks + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
-    const unsigned grid = (unsigned)((nchunks + ENT_WAVES - 1) / ENT_WAVES);
+    // as many workgroups as fit on the device at once (each loops over its share of the chunks)
+    static long long resident_cache[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    long long resident = dev >= 0 && dev < 64 ? resident_cache[dev] : 0;
+    if (resident == 0) {
+        int cus = 0, per_cu = 0;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_entropy, ENT_THREADS, 0);
+        if (e != hipSuccess) return e;
+        resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
+        if (dev >= 0 && dev < 64) resident_cache[dev] = resident;
+    }
+    const unsigned grid = (unsigned)min((nchunks + ENT_WAVES - 1) / ENT_WAVES, resident);
     EntArgs a{coef, g.nblocks, nchunks, g.nb, g.h * g.v, {pred[0], pred[1], pred[2]}, b.epoch, b.clen, b.sparse, b.status};
     hipLaunchKernelGGL(k_entropy, dim3(grid), dim3(ENT_THREADS), 0, s, a);
     return hipGetLastError();
