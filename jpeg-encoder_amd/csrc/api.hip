@@ -128,7 +128,8 @@ extern "C" int jpg_create(jpg_ctx **out, int device, int dct_algo, int ra, int r
     if (ok) {
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-        c->eb.stuff_grid = (size_t)cus * 4;
+        c->eb.stuff_grid = (size_t)cus * 2;
+        if (const char *ev = getenv("JPG_STUFF_GRID")) c->eb.stuff_grid = (size_t)atoi(ev) > 0 ? (size_t)atoi(ev) : c->eb.stuff_grid;
     }
     if (!ok) {
         (void)hipGetLastError();

@@ -430,6 +430,34 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     }
 }
 
+// The same prefix for an early item (i < DIRECT_ITEMS): the values of all items before it are
+// fetched in one go, so the item does not wait for a group sum that itself had to wait.
+constexpr int DIRECT_ITEMS = 1024;
+__device__ __forceinline__ uint64_t sums_prefix_direct(const Sums &s, long long i, uint64_t own, int lane, bool &timeout) {
+    constexpr int ROUNDS = DIRECT_ITEMS / 64;
+    const int nr = (int)((i + 63) >> 6), g = (int)(i >> 6);
+    uint64_t w[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) w[r] = (r < nr && r * 64 + lane < i) ? hw_load(&s.agg[r * 64 + lane]) : 0;
+    uint64_t all = 0, mine = 0;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        if (r < nr) {
+            const uint64_t v = hw_wait(&s.agg[r * 64 + lane], r * 64 + lane < i, w[r], s.epoch, timeout);
+            all += v;
+            if (r == g) mine = v;
+        }
+    }
+    all = wave_sum64(all);
+    const bool closes_group = (i & 63) == 63 || i == s.n - 1;
+    if (closes_group) {
+        const uint64_t gv = wave_sum64(mine) + own;
+        if (lane == 0) hw_store(&s.grp[g], hw_pack(s.epoch, gv));
+        if (i == s.n - 1 && lane == 0) hw_store(&s.hyp[0], hw_pack(s.epoch, all + own));
+    }
+    return all;
+}
+
 // ---------------------------------------------------------------- stream readers
 
 struct StreamArgs {
@@ -490,20 +518,22 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- bits per group, then their running sums
-    for (int g = tid; g < a.ngroups; g += 256) {
-        const long long c0 = (long long)g * 64;
-        uint32_t sum = 0;
-        if (c0 + 64 <= a.nchunks) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(a.clen + c0);
-            uint4 v[16];
+    {
+        for (int g = tid; g < a.ngroups; g += 256) {
+            const long long c0 = (long long)g * 64;
+            uint32_t sum = 0;
+            if (c0 + 64 <= a.nchunks) {
+                const uint4 *p = reinterpret_cast<const uint4 *>(a.clen + c0);
+                uint4 v[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = p[k];
+                for (int k = 0; k < 16; k++) v[k] = p[k];
 #pragma unroll
-            for (int k = 0; k < 16; k++) sum += v[k].x + v[k].y + v[k].z + v[k].w;
-        } else {
-            for (long long c = c0; c < a.nchunks; c++) sum += a.clen[c];
+                for (int k = 0; k < 16; k++) sum += v[k].x + v[k].y + v[k].z + v[k].w;
+            } else {
+                for (long long c = c0; c < a.nchunks; c++) sum += a.clen[c];
+            }
+            sG[g] = sum;
         }
-        sG[g] = sum;
     }
     __syncthreads();
     const int per = (a.ngroups + 255) / 256;
@@ -578,20 +608,24 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
         for (int k = tid; k < DENSE_WORDS; k += 256) sD[k] = 0;
         __syncthreads();
         {
+            // thread t takes wanted words t * rounds .. t * rounds + rounds - 1: one search, then a walk
             const int nwant = sW[256];
+            const int rounds = (nwant + 255) >> 8;                // <= GATHER_ROUNDS
             uint32_t wv[GATHER_ROUNDS];
             int pos[GATHER_ROUNDS];
+            int f = tid * rounds;
+            int i = f < nwant ? find_last_le(sW, f) : TABLE - 1;  // the last of equal entries is the non-empty one
 #pragma unroll
             for (int m = 0; m < GATHER_ROUNDS; m++) {
-                const int f = tid + 256 * m;
                 wv[m] = 0;
                 pos[m] = 0;
-                if (f < nwant) {
-                    const int i = find_last_le(sW, f);            // the last of equal entries is the non-empty one
+                if (m < rounds && f < nwant) {
+                    while (sW[i + 1] <= f) i++;
                     const int j = sW0[i] + (f - sW[i]);
                     wv[m] = slots[(size_t)i * CHUNK_STRIDE_WORDS + j];
                     pos[m] = sT[i] + 32 * j;                      // where the word's first bit goes (>= -31)
                 }
+                f++;
             }
 #pragma unroll
             for (int m = 0; m < GATHER_ROUNDS; m++) {
@@ -646,8 +680,12 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
             uint64_t before = 0;
             if (nseg) {
                 if (lane == 0) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
-                const Probe probe = sums_probe(sums, (long long)seg, lane);
-                before = sums_prefix(sums, (long long)seg, total, probe, lane, timeout);
+                if (seg < DIRECT_ITEMS) {
+                    before = sums_prefix_direct(sums, (long long)seg, total, lane, timeout);
+                } else {
+                    const Probe probe = sums_probe(sums, (long long)seg, lane);
+                    before = sums_prefix(sums, (long long)seg, total, probe, lane, timeout);
+                }
             }
             if (lane == 0) {
                 sBefore = before;
@@ -718,22 +756,22 @@ static StreamArgs stream_args(const EntropyBufs &b, uint64_t bit_offset, uint8_t
                       head_bits, is_last, b.sagg, b.sgrp, b.shyp, b.stuff_epoch, b.epoch, out, b.host_status};
 }
 
-hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s) {
-    const StreamArgs a = stream_args(b, bit_offset, head_bits, is_last, b.scan);
-    if (a.ngroups > MAX_GROUPS) return hipErrorInvalidValue;
+template <bool STUFF>
+static hipError_t launch_stream(const EntropyBufs &b, StreamArgs a, hipStream_t s) {
+    if (a.ngroups > MAX_GROUPS || !a.out) return hipErrorInvalidValue;
+    const size_t lds = (a.ngroups + 1) * sizeof(uint64_t);
     const size_t cap = b.stuff_grid ? b.stuff_grid : 1024;
     const unsigned grid = (unsigned)(b.nseg_cap < cap ? (b.nseg_cap ? b.nseg_cap : 1) : cap);
-    hipLaunchKernelGGL(k_stream<true>, dim3(grid), dim3(256), (a.ngroups + 1) * sizeof(uint64_t), s, a);
+    hipLaunchKernelGGL(k_stream<STUFF>, dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
+hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s) {
+    return launch_stream<true>(b, stream_args(b, bit_offset, head_bits, is_last, b.scan), s);
+}
+
 hipError_t launch_dense(const EntropyBufs &b, hipStream_t s) {
-    const StreamArgs a = stream_args(b, 0, 0, 1, reinterpret_cast<uint8_t *>(b.bits));
-    if (a.ngroups > MAX_GROUPS || !b.bits) return hipErrorInvalidValue;
-    const size_t cap = b.stuff_grid ? b.stuff_grid : 1024;
-    const unsigned grid = (unsigned)(b.nseg_cap < cap ? (b.nseg_cap ? b.nseg_cap : 1) : cap);
-    hipLaunchKernelGGL(k_stream<false>, dim3(grid), dim3(256), (a.ngroups + 1) * sizeof(uint64_t), s, a);
-    return hipGetLastError();
+    return launch_stream<false>(b, stream_args(b, 0, 0, 1, reinterpret_cast<uint8_t *>(b.bits)), s);
 }
 
 }  // namespace jpg
