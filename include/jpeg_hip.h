@@ -100,6 +100,10 @@ int jpg_stuff(jpg_ctx *ctx, size_t *len);
  * are never written to memory).  Asynchronous: returns after queueing. */
 int jpg_front_device(jpg_ctx *ctx, const uint8_t *dev_pixels, int32_t width, int32_t height,
                      uint32_t row_stride, int bottom_up);
+/* the same from host memory: the rows are copied to the device first (the copy
+ * is complete when the call returns, so `pixels` may be reused) */
+int jpg_front_host(jpg_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t height, uint32_t row_stride,
+                   int bottom_up);
 /* jpg_front_device + entropy coding + stuffing, all queued on the context's
  * stream without any host synchronisation.  jpg_finish() waits and reports. */
 int jpg_encode_device_async(jpg_ctx *ctx, const uint8_t *dev_pixels, int32_t width, int32_t height,
@@ -122,6 +126,9 @@ void jpg_free(void *p);
  * three DC predictors start at pred[0..2] (Y, Cb, Cr) instead of 0.  The bit
  * string starts at bit 0 of the context's buffer. */
 int jpg_entropy_stripe(jpg_ctx *ctx, const int16_t pred[3], uint64_t *nbits);
+/* The last min(32, nbits) bits of the stripe's unstuffed bit string, right-aligned
+ * in *last32: what a following stripe needs to fill the byte the two share. */
+int jpg_stream_tail(jpg_ctx *ctx, uint32_t *last32);
 /* DC coefficient of the last Y, Cb, Cr block of the stripe in scan order */
 int jpg_last_dc(jpg_ctx *ctx, int16_t dc[3]);
 /* Place this stripe's bit string at global bit offset `bit_offset` of the

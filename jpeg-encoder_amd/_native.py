@@ -4,6 +4,7 @@ There is no CPU fallback: if the library is missing or a call fails, an
 exception is raised.
 """
 import ctypes as C
+import importlib.util
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -16,8 +17,8 @@ DCT_REAL, DCT_BIN, DCT_REAL_STRICT = 0, 1, 2
 SYMBOLS = [
     "jpg_strerror", "jpg_last_hip_error", "jpg_create", "jpg_destroy", "jpg_stream", "jpg_sync",
     "jpg_load_bgr", "jpg_load_bgr_device", "jpg_downsample", "jpg_dct_quant", "jpg_entropy", "jpg_stuff",
-    "jpg_front_device", "jpg_encode_device_async", "jpg_finish", "jpg_encode_scan", "jpg_free",
-    "jpg_entropy_stripe", "jpg_last_dc", "jpg_stitch", "jpg_bits_device", "jpg_scan_device",
+    "jpg_front_device", "jpg_front_host", "jpg_encode_device_async", "jpg_finish", "jpg_encode_scan", "jpg_free",
+    "jpg_entropy_stripe", "jpg_stream_tail", "jpg_last_dc", "jpg_stitch", "jpg_bits_device", "jpg_scan_device",
     "jpg_get_bits", "jpg_get_scan", "jpg_plane_dims", "jpg_coeff_dims", "jpg_get_plane", "jpg_get_coeffs",
     "jpg_front_bytes", "jpg_num_blocks",
 ]
@@ -35,6 +36,23 @@ class JpgError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime():
+    """PyTorch wheels ship their own libamdhip64.so.7.  Two HIP runtimes in one process do not see
+    each other's devices, so when PyTorch is installed its copy is loaded first and libjpeg_hip.so
+    binds to it by soname, whichever of the two libraries the program touches first.  Without
+    PyTorch the system runtime (RUNPATH /opt/rocm) is used."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        for d in spec.submodule_search_locations:
+            p = os.path.join(d, "lib", "libamdhip64.so")
+            if os.path.exists(p):
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+                return
+
+
 def lib():
     """Load libjpeg_hip.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -42,6 +60,7 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: build it with `python jpeg-encoder_amd/build.py`" % LIB_PATH)
+    _share_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32, u32, u64p, szp = C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)
     L.jpg_strerror.argtypes = [C.c_int]
@@ -53,7 +72,8 @@ def lib():
     L.jpg_stream.argtypes = [vp]
     L.jpg_stream.restype = vp
     L.jpg_sync.argtypes = [vp]
-    for name in ("jpg_load_bgr", "jpg_load_bgr_device", "jpg_front_device", "jpg_encode_device_async"):
+    for name in ("jpg_load_bgr", "jpg_load_bgr_device", "jpg_front_device", "jpg_front_host",
+                 "jpg_encode_device_async"):
         getattr(L, name).argtypes = [vp, vp, i32, i32, u32, C.c_int]
     L.jpg_downsample.argtypes = [vp]
     L.jpg_dct_quant.argtypes = [vp]
@@ -65,6 +85,7 @@ def lib():
     L.jpg_free.restype = None
     L.jpg_entropy_stripe.argtypes = [vp, C.POINTER(C.c_int16), u64p]
     L.jpg_last_dc.argtypes = [vp, C.POINTER(C.c_int16)]
+    L.jpg_stream_tail.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.jpg_stitch.argtypes = [vp, C.c_uint64, C.c_uint8, C.c_int, szp, C.POINTER(C.c_uint8)]
     L.jpg_bits_device.argtypes = [vp]
     L.jpg_bits_device.restype = vp

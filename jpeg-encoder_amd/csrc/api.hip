@@ -379,6 +379,27 @@ extern "C" int jpg_entropy_stripe(jpg_ctx *c, const int16_t pred[3], uint64_t *n
     return entropy_common(c, pred, nbits);
 }
 
+extern "C" int jpg_stream_tail(jpg_ctx *c, uint32_t *last32) {
+    if (!c || !last32) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_BITS || c->pending) return JPG_ERR_STATE;
+    if (int e = use_device(c)) return e;
+    if (int e = make_dense(c)) return e;
+    const uint64_t nbytes = (c->nbits + 7) >> 3;
+    const uint64_t take = nbytes < 5 ? nbytes : 5;   // 32 bits may straddle 5 bytes
+    uint8_t b[8] = {0};
+    if (take) {
+        HIP_TRY(c, hipMemcpyAsync(b, reinterpret_cast<const uint8_t *>(c->eb.bits) + (nbytes - take), take,
+                                  hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    uint64_t v = 0;
+    for (uint64_t i = 0; i < take; i++) v = (v << 8) | b[i];
+    const unsigned pad = (unsigned)(nbytes * 8 - c->nbits);   // zero bits after the stream in its last byte
+    v >>= pad;
+    *last32 = (uint32_t)(c->nbits >= 32 ? v : v & ((1ull << c->nbits) - 1));
+    return JPG_OK;
+}
+
 extern "C" int jpg_last_dc(jpg_ctx *c, int16_t dc[3]) {
     if (!c || !dc) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_COEF) return JPG_ERR_STATE;
@@ -412,6 +433,18 @@ extern "C" int jpg_front_device(jpg_ctx *c, const uint8_t *dev_pixels, int32_t W
     if (int e = use_device(c)) return e;
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
     if (int e = stage_input(c, dev_pixels, false)) return e;
+    if (int e = ensure_coef(c)) return e;
+    HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream));
+    c->stage = ST_COEF;
+    return JPG_OK;
+}
+
+extern "C" int jpg_front_host(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride, int bottom_up) {
+    if (!c || !pixels) return JPG_ERR_BAD_ARG;
+    if (int e = use_device(c)) return e;
+    if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
+    if (int e = stage_input(c, pixels, true)) return e;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // caller may reuse `pixels`
     if (int e = ensure_coef(c)) return e;
     HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream));
     c->stage = ST_COEF;

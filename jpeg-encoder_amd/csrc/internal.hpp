@@ -39,8 +39,8 @@ constexpr int CHUNK_STRIDE_WORDS = 3328;
 static_assert(CHUNK_STRIDE_WORDS * 32 >= CHUNK_BLOCKS * MAX_BLOCK_BITS + 64, "chunk slot too small");
 // byte-stuffing works on segments of this many unstuffed bytes
 constexpr int STUFF_SEG = 4096;
-// groups of 64 chunks a stream reader can tabulate in LDS (limits an image to 16.7M blocks)
-constexpr int MAX_GROUPS = 4096;
+// groups of 64 chunks a stream reader can tabulate in LDS (52 KiB of LDS; limits an image to 27M blocks)
+constexpr int MAX_GROUPS = 6656;
 
 // results a host needs after an encode, fetched with one copy
 struct DevStatus {

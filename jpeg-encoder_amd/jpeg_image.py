@@ -99,6 +99,12 @@ class Encoder:
         self._ck(self._L.jpg_stitch(self._ctx, bit_offset, head_bits, int(is_last), C.byref(n), C.byref(tail)))
         return n.value, tail.value
 
+    def stream_tail(self):
+        """The last min(32, nbits) bits of the stripe's bit string, right-aligned."""
+        v = C.c_uint32()
+        self._ck(self._L.jpg_stream_tail(self._ctx, C.byref(v)))
+        return v.value
+
     def last_dc(self):
         dc = (C.c_int16 * 3)()
         self._ck(self._L.jpg_last_dc(self._ctx, dc))
@@ -108,6 +114,13 @@ class Encoder:
     def front_device(self, dev_ptr, width, height, stride, bottom_up=True):
         self.width, self.height = width, height
         self._ck(self._L.jpg_front_device(self._ctx, dev_ptr, width, height, stride, int(bottom_up)))
+
+    def front_host(self, rows, width, height, stride=None, bottom_up=True):
+        rows = np.ascontiguousarray(rows, np.uint8)
+        stride = stride or rows.shape[-1]
+        assert rows.size >= stride * (height - 1) + 3 * width
+        self.width, self.height = width, height
+        self._ck(self._L.jpg_front_host(self._ctx, rows.ctypes.data, width, height, stride, int(bottom_up)))
 
     def encode_device_async(self, dev_ptr, width, height, stride, bottom_up=True):
         self.width, self.height = width, height

@@ -1,0 +1,163 @@
+"""CPU tests of the host side: the C-ABI libraries load and export what the headers declare, the BMP
+reader and JFIF writer behave like the reference's (checked against the oracle), and there is no
+CPU fallback for the device path."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(jp[gh]_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_hip_library_exports_every_declared_symbol(J):
+    from jpeg_encoder_amd import _native
+    names = _declared("jpeg_hip.h")
+    assert len(names) >= 30
+    L = C.CDLL(_native.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(_native.SYMBOLS) == names                     # the Python binding covers the whole header
+
+
+def test_host_library_exports_every_declared_symbol(J):
+    names = _declared("jpeg_host.h")
+    L = C.CDLL(J.host.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(J.host.SYMBOLS) == names
+
+
+def test_error_strings_are_the_reference_panics(J):
+    from jpeg_encoder_amd import _native
+    L = _native.lib()
+    assert L.jpg_strerror(0) == b"ok"
+    assert L.jpg_strerror(-1) == b"Invalid chrominance downsampling ratio!"        # src/jpeg/sampling.rs:19
+    assert L.jpg_strerror(-2) == b"DC coefficient bit length greater than 11!"     # src/jpeg/entropy_coding.rs:154
+    assert L.jpg_strerror(-3) == b"AC coefficient bit length greater than 10!"     # src/jpeg/entropy_coding.rs:190
+    assert L.jpg_strerror(-4) == b"DC Huffman Code Not Found!"
+    assert L.jpg_strerror(-5) == b"AC Huffman Code Not Found!"
+    for code in range(-11, 1):
+        assert L.jpg_strerror(code) != b"unknown status"
+
+
+def test_create_rejects_bad_arguments_before_touching_a_device(J):
+    from jpeg_encoder_amd import _native
+    L = _native.lib()
+    ctx = C.c_void_p()
+    assert L.jpg_create(C.byref(ctx), 0, 0, 4, 1, 1) == -1      # invalid ratio
+    assert L.jpg_create(C.byref(ctx), 0, 7, 4, 2, 0) == -6      # unknown DCT
+    assert L.jpg_create(None, 0, 0, 4, 2, 0) == -6
+    assert J.get_downsampling_factor((4, 2, 0)) == (2, 2)
+    with pytest.raises(Exception, match="Invalid chrominance downsampling ratio!"):
+        J.get_downsampling_factor((4, 1, 0))
+
+
+def test_no_cpu_fallback(J):
+    """Without a GPU the device path fails loudly instead of computing on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(J.JpgError):
+        J.Encoder((4, 2, 0), "real-dct")
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "jpeg-encoder_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                for needle in ("refcpu", "import oracle", "from oracle", "oracle/", "oracle."):
+                    assert needle not in txt, (os.path.join(dirpath, f), needle)
+
+
+# ---- BMP reader (src/bmp/bmp_image.rs:21-90)
+
+@pytest.mark.parametrize("w,h", [(1, 1), (2, 3), (5, 4), (16, 16), (50, 35), (127, 9)])
+def test_bmp_roundtrip_and_oracle_agreement(J, oracle, tmp_path, w, h):
+    rows = J.host.synth_bgr(w, h, seed=w * 1000 + h)
+    stride = J.host.bmp_stride(w)
+    assert rows.shape == (h, stride) and stride % 4 == 0 and stride >= 3 * w
+    p = str(tmp_path / "a.bmp")
+    J.host.write_bmp(p, rows, w, h)
+    assert os.path.getsize(p) == 54 + stride * h
+    got, gw, gh, gs = J.host.read_bmp(p)
+    assert (gw, gh, gs) == (w, h, stride)
+    assert (got[:, :3 * w] == rows[:, :3 * w]).all()
+    # the oracle's reader (per-pixel reads, bottom-up flip, BGR -> RGB) sees the same picture
+    rgb = oracle.bmp_load_rgb(p)
+    assert (rgb == rows[::-1, :3 * w].reshape(h, w, 3)[:, :, ::-1]).all()
+
+
+def test_bmp_reader_uses_only_three_header_fields(J, oracle, tmp_path):
+    """data offset @10, width @18, height @22; everything else is ignored, as in the reference."""
+    w, h = 7, 5
+    rows = J.host.synth_bgr(w, h, seed=3)
+    stride = J.host.bmp_stride(w)
+    off = 138                                                    # e.g. a BITMAPV5HEADER file
+    hdr = bytearray(os.urandom(off))
+    struct.pack_into("<I", hdr, 10, off)
+    struct.pack_into("<i", hdr, 18, w)
+    struct.pack_into("<i", hdr, 22, h)
+    p = str(tmp_path / "v5.bmp")
+    open(p, "wb").write(bytes(hdr) + rows.tobytes())
+    got, gw, gh, gs = J.host.read_bmp(p)
+    assert (gw, gh, gs) == (w, h, stride) and (got[:, :3 * w] == rows[:, :3 * w]).all()
+    assert (oracle.bmp_load_rgb(p) == rows[::-1, :3 * w].reshape(h, w, 3)[:, :, ::-1]).all()
+
+
+def test_bmp_errors(J, tmp_path):
+    with pytest.raises(J.host.BmpError, match="Could not open bitmap image file!"):
+        J.host.read_bmp(str(tmp_path / "missing.bmp"))
+    hdr = bytearray(54)
+    struct.pack_into("<I", hdr, 10, 54)
+    struct.pack_into("<i", hdr, 18, 0)
+    struct.pack_into("<i", hdr, 22, 4)
+    p = str(tmp_path / "zero.bmp")
+    open(p, "wb").write(bytes(hdr))
+    with pytest.raises(J.host.BmpError):
+        J.host.read_bmp(p)
+
+
+def test_synth_is_deterministic_and_seeded(J):
+    a = J.host.synth_bgr(64, 48, seed=5)
+    b = J.host.synth_bgr(64, 48, seed=5)
+    c = J.host.synth_bgr(64, 48, seed=6)
+    n = J.host.synth_bgr(64, 48, seed=5, noise_only=True)
+    assert (a == b).all() and (a != c).any() and (a != n).any()
+    assert n[:, :192].std() > 60                                 # uniform noise
+
+
+# ---- JFIF writer (src/jpeg/file.rs:10-137)
+
+@pytest.mark.parametrize("ratio", [(4, 4, 4), (4, 2, 2), (4, 2, 0)])
+def test_header_and_file_bytes_match_the_oracle(J, oracle, tmp_path, ratio):
+    w, h = 50, 35
+    rows = J.host.synth_bgr(w, h, seed=9)
+    im = oracle.RefImage.from_bgr(rows, w, h, rows.shape[1], ratio, oracle.BIN).encode()
+    want = im.file_bytes()
+    scan = im.stuffed_scan()
+    hf, vf = J.get_downsampling_factor(ratio)
+    hdr = J.host.jfif_header(w, h, hf, vf)
+    assert len(hdr) == 623 and hdr == want[:623]
+    assert J.host.assemble_jpeg(w, h, hf, vf, scan) == want
+    p = str(tmp_path / "o.jpeg")
+    J.host.write_jpeg(p, w, h, hf, vf, scan)
+    assert open(p, "rb").read() == want
+
+
+def test_sof_dimensions_are_truncated_to_u16(J):
+    """`as u16` in src/jpeg/file.rs:43-44: 65536 + 3 is written as 3."""
+    hdr = J.host.jfif_header(65536 + 3, 70000, 2, 2)
+    sof = hdr.index(b"\xff\xc0")
+    assert hdr[sof + 5:sof + 9] == struct.pack(">HH", 70000 & 0xffff, 3)
