@@ -84,7 +84,7 @@ def build_host(force=False):
     if force or _stale(LIB_HOST, srcs + HOST_HEADERS + [os.path.abspath(__file__)]):
         _run([CXX] + CXX_FLAGS + ["-shared", "-o", LIB_HOST] + [_abs(s) for s in srcs])
     main = _abs("host/main.cpp")
-    if os.path.exists(main) and (force or _stale(CLI, srcs + HOST_HEADERS + ["host/main.cpp", "host/args.hpp",
+    if os.path.exists(main) and (force or _stale(CLI, srcs + HOST_HEADERS + ["host/main.cpp",
                                                                               os.path.abspath(__file__)])
                                  or os.path.getmtime(LIB_HIP) > os.path.getmtime(CLI)):
         _run([HIPCC, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", CLI, main,

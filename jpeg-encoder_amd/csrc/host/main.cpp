@@ -1,0 +1,214 @@
+// jpeg-encoder: command-line front end with the reference's interface
+// (src/main.rs:8-68, src/utils/arguments.rs:6-66).  Same flags, aliases,
+// defaults, printed lines and exit codes; the five JpegImage calls of main()
+// become the five staged calls of libjpeg_hip.so.  Extra flags (not in the
+// reference): --device N, --fused.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "jpeg_hip.h"
+#include "jpeg_host.h"
+
+namespace {
+
+constexpr int EXIT_PANIC = 101;   // a Rust panic in the reference
+constexpr int EXIT_USAGE = 2;     // a clap parse error in the reference
+
+const char *USAGE =
+    "Usage: jpeg-encoder [OPTIONS] --image <IMAGE>\n"
+    "\n"
+    "Options:\n"
+    "  -i, --image <IMAGE>                          the input image path\n"
+    "  -o, --output <OUTPUT>                        the output image path (optional) [default: ]\n"
+    "  -s, --subsampling-ratio <SUBSAMPLING_RATIO>  Subsampling ratio in the format `4:2:0`, `4:4:4`, or `4:2:2` "
+    "[default: 4:2:0]\n"
+    "  -d, --dct-algorithm <DCT_ALGORITHM>          DCT algorithm to use: either \"RealDct\" or \"BinDct\" "
+    "[default: real-dct] [possible values: real-dct, bin-dct]\n"
+    "      --device <N>                             GPU to use [default: 0]\n"
+    "      --fused                                  one fused device pass instead of the five stages\n"
+    "  -h, --help                                   Print help\n"
+    "  -V, --version                                Print version\n";
+
+[[noreturn]] void usage_error(const std::string &msg) {
+    std::fprintf(stderr, "error: %s\n\n%s\nFor more information, try '--help'.\n", msg.c_str(), USAGE);
+    std::exit(EXIT_USAGE);
+}
+
+[[noreturn]] void panic(const char *msg) {
+    std::fprintf(stderr, "thread 'main' panicked:\n%s\n", msg);
+    std::exit(EXIT_PANIC);
+}
+
+struct Args {
+    std::string image, output, ratio_text = "4:2:0", dct = "real-dct";
+    int ratio[3] = {4, 2, 0};
+    int device = 0;
+    bool fused = false;
+};
+
+// parse_subsampling_ratio (src/utils/arguments.rs:25-43)
+void parse_ratio(const std::string &s, int out[3]) {
+    std::vector<std::string> parts;
+    size_t a = 0;
+    for (;;) {
+        const size_t b = s.find(':', a);
+        parts.push_back(s.substr(a, b == std::string::npos ? b : b - a));
+        if (b == std::string::npos) break;
+        a = b + 1;
+    }
+    if (parts.size() != 3)
+        usage_error("invalid value '" + s + "' for '--subsampling-ratio <SUBSAMPLING_RATIO>': Subsampling ratio must be "
+                    "in the format A:B:C");
+    for (int k = 0; k < 3; k++) {
+        const std::string &p = parts[k];
+        // Rust's u8::from_str: an optional '+', then digits, value <= 255
+        size_t i = (!p.empty() && p[0] == '+') ? 1 : 0;
+        bool ok = i < p.size();
+        long v = 0;
+        for (; ok && i < p.size(); i++) {
+            if (p[i] < '0' || p[i] > '9') ok = false;
+            else v = v * 10 + (p[i] - '0');
+            if (v > 255) ok = false;
+        }
+        if (!ok)
+            usage_error("invalid value '" + s + "' for '--subsampling-ratio <SUBSAMPLING_RATIO>': Subsampling ratio "
+                        "must consist of three integers separated by colons");
+        out[k] = (int)v;
+    }
+    // get_downsampling_factor panics inside the parser (src/utils/arguments.rs:37, src/jpeg/sampling.rs:6-22)
+    const bool valid = out[0] == 4 && ((out[1] == 4 && out[2] == 4) || (out[1] == 2 && (out[2] == 0 || out[2] == 2)));
+    if (!valid) panic(jpg_strerror(JPG_ERR_INVALID_RATIO));
+}
+
+Args parse(int argc, char **argv) {
+    Args a;
+    bool have_image = false;
+    auto value = [&](int &i, const char *name, const char *inline_val) -> std::string {
+        if (inline_val) return inline_val;
+        if (i + 1 >= argc) usage_error(std::string("a value is required for '") + name + "' but none was supplied");
+        return argv[++i];
+    };
+    for (int i = 1; i < argc; i++) {
+        const std::string arg = argv[i];
+        std::string key = arg;
+        const char *inl = nullptr;
+        if (arg.rfind("--", 0) == 0) {
+            const size_t eq = arg.find('=');
+            if (eq != std::string::npos) {
+                key = arg.substr(0, eq);
+                inl = argv[i] + eq + 1;
+            }
+        } else if (arg.size() > 2 && arg[0] == '-') {   // -ifile.bmp or -i=file.bmp
+            key = arg.substr(0, 2);
+            inl = argv[i] + 2;
+            if (*inl == '=') inl++;
+        }
+        if (key == "-h" || key == "--help") {
+            std::printf("%s", USAGE);
+            std::exit(0);
+        } else if (key == "-V" || key == "--version") {
+            std::printf("jpeg-encoder 0.1.0\n");
+            std::exit(0);
+        } else if (key == "-i" || key == "--image") {
+            a.image = value(i, "--image <IMAGE>", inl);
+            have_image = true;
+        } else if (key == "-o" || key == "--output") {
+            a.output = value(i, "--output <OUTPUT>", inl);
+        } else if (key == "-s" || key == "--subsampling-ratio") {
+            a.ratio_text = value(i, "--subsampling-ratio <SUBSAMPLING_RATIO>", inl);
+        } else if (key == "-d" || key == "--dct-algorithm") {
+            a.dct = value(i, "--dct-algorithm <DCT_ALGORITHM>", inl);
+            if (a.dct != "real-dct" && a.dct != "bin-dct")
+                usage_error("invalid value '" + a.dct + "' for '--dct-algorithm <DCT_ALGORITHM>'\n  [possible values: "
+                            "real-dct, bin-dct]");
+        } else if (key == "--device") {
+            a.device = std::atoi(value(i, "--device <N>", inl).c_str());
+        } else if (key == "--fused") {
+            a.fused = true;
+        } else {
+            usage_error("unexpected argument '" + arg + "' found");
+        }
+    }
+    if (!have_image) usage_error("the following required arguments were not provided:\n  --image <IMAGE>");
+    parse_ratio(a.ratio_text, a.ratio);
+    // Args::get_args (src/utils/arguments.rs:46-58)
+    const std::string ext = ".bmp";
+    if (a.image.size() < ext.size() || a.image.compare(a.image.size() - ext.size(), ext.size(), ext) != 0)
+        panic("Input image must be a .bmp file\n");
+    if (a.output.empty()) a.output = a.image.substr(0, a.image.size() - ext.size()) + ".jpeg";
+    return a;
+}
+
+[[noreturn]] void fail(jpg_ctx *ctx, int status) {
+    std::string msg = jpg_strerror(status);
+    if (status == JPG_ERR_HIP) msg += " (hipError " + std::to_string(jpg_last_hip_error(ctx)) + ")";
+    if (ctx) jpg_destroy(ctx);
+    panic(msg.c_str());
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    const Args args = parse(argc, argv);
+    // Args::print_args (src/utils/arguments.rs:60-66)
+    std::printf("image: \"%s\"\n", args.image.c_str());
+    std::printf("output: \"%s\"\n", args.output.c_str());
+    std::printf("subsampling ratio: \"(%d, %d, %d)\"\n", args.ratio[0], args.ratio[1], args.ratio[2]);
+    std::printf("dct algorithm: \"%s\"\n", args.dct == "bin-dct" ? "BinDct" : "RealDct");
+    std::printf("\n");
+
+    std::printf("Loading bmp...\n");
+    std::fflush(stdout);
+    jph_bmp bmp{};
+    const int be = jph_bmp_read(args.image.c_str(), &bmp);
+    if (be == JPH_ERR_OPEN) panic("Could not open bitmap image file!\n");
+    if (be != JPH_OK) panic("could not read the bitmap image file");
+    jpg_ctx *ctx = nullptr;
+    int st = jpg_create(&ctx, args.device, args.dct == "bin-dct" ? JPG_DCT_BIN : JPG_DCT_REAL, args.ratio[0], args.ratio[1],
+                        args.ratio[2]);
+    if (st != JPG_OK) fail(ctx, st);
+    const int h = 1 + (args.ratio[1] == 2), v = 1 + (args.ratio[1] == 2 && args.ratio[2] == 0);
+
+    uint8_t *scan = nullptr;
+    size_t scan_len = 0;
+    std::vector<uint8_t> staged_scan;
+    if (args.fused) {
+        st = jpg_encode_scan(ctx, bmp.pixels, bmp.width, bmp.height, bmp.row_stride, 1, &scan, &scan_len);
+        if (st != JPG_OK) fail(ctx, st);
+        std::printf("Loaded!\nChrominance downsampling...\nDone!\n");
+        std::printf("Performing Discrete Cosine Transform + Quantization...\nDone!\nEntropy encoding...\nDone!\n");
+    } else {
+        // the five calls of main (src/main.rs:17,35,48,61,66)
+        if ((st = jpg_load_bgr(ctx, bmp.pixels, bmp.width, bmp.height, bmp.row_stride, 1)) != JPG_OK) fail(ctx, st);
+        std::printf("Loaded!\n");
+        std::printf("Chrominance downsampling...\n");
+        if ((st = jpg_downsample(ctx)) != JPG_OK) fail(ctx, st);
+        std::printf("Done!\n");
+        std::printf("Performing Discrete Cosine Transform + Quantization...\n");
+        if ((st = jpg_dct_quant(ctx)) != JPG_OK) fail(ctx, st);
+        std::printf("Done!\n");
+        std::printf("Entropy encoding...\n");
+        uint64_t nbits = 0;
+        if ((st = jpg_entropy(ctx, &nbits)) != JPG_OK) fail(ctx, st);
+        std::printf("Done!\n");
+    }
+    std::printf("Creating file\n");
+    std::fflush(stdout);
+    if (!args.fused) {
+        if ((st = jpg_stuff(ctx, &scan_len)) != JPG_OK) fail(ctx, st);
+        staged_scan.resize(scan_len ? scan_len : 1);
+        if ((st = jpg_get_scan(ctx, staged_scan.data(), staged_scan.size())) != JPG_OK) fail(ctx, st);
+    }
+    const uint8_t *bytes = args.fused ? scan : staged_scan.data();
+    const int we = jph_jpeg_write(args.output.c_str(), bmp.width, bmp.height, h, v, bytes, scan_len);
+    if (scan) jpg_free(scan);
+    jpg_destroy(ctx);
+    jph_bmp_free(&bmp);
+    if (we != JPH_OK) panic("called `Result::unwrap()` on an `Err` value: could not write the output file");
+    std::printf("Done!\n");
+    return 0;
+}

@@ -1,0 +1,74 @@
+"""The command-line front end keeps the reference's interface (src/utils/arguments.rs:6-66,
+src/main.rs:8-68): flags, aliases, defaults, printed lines, exit codes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CLI = os.path.join(os.path.dirname(HERE), "jpeg-encoder_amd", "jpeg-encoder")
+
+BANNERS = ["Loading bmp...", "Loaded!", "Chrominance downsampling...", "Done!",
+           "Performing Discrete Cosine Transform + Quantization...", "Done!", "Entropy encoding...", "Done!",
+           "Creating file", "Done!"]
+
+
+def run(*args, cwd=None):
+    return subprocess.run([CLI] + list(args), cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                          timeout=120)
+
+
+def test_argument_errors_and_exit_codes(tmp_path):
+    assert os.path.exists(CLI), "build it with python jpeg-encoder_amd/build.py"
+    r = run()
+    assert r.returncode == 2 and "--image <IMAGE>" in r.stderr                 # clap usage error
+    r = run("-i", "picture.png")
+    assert r.returncode == 101 and "Input image must be a .bmp file" in r.stderr    # panic
+    r = run("-i", "a.bmp", "-s", "4:1:1")
+    assert r.returncode == 101 and "Invalid chrominance downsampling ratio!" in r.stderr
+    r = run("-i", "a.bmp", "-s", "4:2")
+    assert r.returncode == 2 and "Subsampling ratio must be in the format A:B:C" in r.stderr
+    r = run("-i", "a.bmp", "-s", "4:x:0")
+    assert r.returncode == 2 and "three integers separated by colons" in r.stderr
+    r = run("-i", "a.bmp", "-d", "fast-dct")
+    assert r.returncode == 2 and "possible values: real-dct, bin-dct" in r.stderr
+    r = run("--help")
+    assert r.returncode == 0 and "--subsampling-ratio" in r.stdout and "--dct-algorithm" in r.stdout
+    r = run("--image", str(tmp_path / "missing.bmp"), "--dct-algorithm=bin-dct", "--subsampling-ratio", "4:4:4")
+    assert r.returncode == 101 and "Could not open bitmap image file!" in r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == 'image: "%s"' % (tmp_path / "missing.bmp")
+    assert lines[1] == 'output: "%s"' % (tmp_path / "missing.jpeg")             # default: .bmp -> .jpeg
+    assert lines[2] == 'subsampling ratio: "(4, 4, 4)"'
+    assert lines[3] == 'dct algorithm: "BinDct"'
+    assert lines[4] == "" and lines[5] == "Loading bmp..."
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,ratio,algo", [((), (4, 2, 0), "real-dct"),
+                                              (("-s", "4:2:2", "-d", "bin-dct"), (4, 2, 2), "bin-dct"),
+                                              (("-s4:4:4", "-dbin-dct", "--fused"), (4, 4, 4), "bin-dct")])
+def test_cli_writes_the_reference_file(J, oracle, tmp_path, flags, ratio, algo):
+    w, h = 150, 94
+    rows = J.host.synth_bgr(w, h, seed=12)
+    bmp = str(tmp_path / "in.bmp")
+    J.host.write_bmp(bmp, rows, w, h)
+    r = run("-i", bmp, *flags)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[1] == 'output: "%s"' % (tmp_path / "in.jpeg")
+    assert lines[5:] == BANNERS
+    data = open(tmp_path / "in.jpeg", "rb").read()
+    a = oracle.BIN if algo == "bin-dct" else oracle.REAL
+    ref = oracle.RefImage.from_bmp(bmp, ratio, a).encode()
+    if algo == "bin-dct":
+        assert data == ref.file_bytes()
+    else:                                                                       # separable real-dct: within tolerance
+        from PIL import Image
+        im = Image.open(tmp_path / "in.jpeg")
+        im.load()
+        assert im.size == (w, h) and abs(len(data) - len(ref.file_bytes())) < 64
+    out2 = str(tmp_path / "other.jpg")
+    r = run("--image", bmp, "--output", out2, "-d", "bin-dct")
+    assert r.returncode == 0 and os.path.getsize(out2) > 623

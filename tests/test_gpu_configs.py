@@ -1,0 +1,96 @@
+"""The named configurations at their full sizes (GPU): byte-exact bin-dct at 3840x2160 4:4:4, the
+coefficient tolerance and PSNR bar at 7680x4320 4:2:0 real-dct, a 1920x1080 4:2:2 batch, and the
+32768x32768 image through stripes."""
+import io
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config_3840x2160_444_bin_dct_byte_exact(J, oracle):
+    w, h = 3840, 2160
+    rows = J.host.synth_bgr(w, h, seed=(2 << 32))
+    ref = oracle.RefImage.from_bgr(rows, w, h, rows.shape[1], (4, 4, 4), oracle.BIN).encode(threads=3)
+    enc = J.Encoder((4, 4, 4), "bin-dct")
+    assert enc.encode_file_bytes(rows, w, h) == ref.file_bytes()
+
+
+def _psnr(data, rows, w, h):
+    from PIL import Image
+    im = Image.open(io.BytesIO(data))
+    im.load()
+    got = np.asarray(im, np.float32)
+    src = rows[::-1, :3 * w].reshape(h, w, 3)[:, :, ::-1].astype(np.float32)
+    return 10 * np.log10(255.0 ** 2 / float(((got - src) ** 2).mean(dtype=np.float64)))
+
+
+def test_config_7680x4320_420_real_dct_tolerance_and_psnr(J, oracle):
+    """Quantised coefficients within +-1 in at most 0.01 % of coefficients; decoded PSNR within 0.01 dB."""
+    w, h = 7680, 4320
+    rows = J.host.synth_bgr(w, h, seed=(3 << 32))
+    ref = oracle.RefImage.from_bgr(rows, w, h, rows.shape[1], (4, 2, 0), oracle.REAL)
+    ref.encode(cos_mode=oracle.COS_TABLE, threads=3)
+    enc = J.Encoder((4, 2, 0), "real-dct")
+    data = enc.encode_file_bytes(rows, w, h)
+    total = bad = 0
+    for c in range(3):
+        d = np.abs(enc.coeffs(c).astype(np.int32) - ref.coeffs(c).astype(np.int32))
+        assert d.max() <= 1
+        total += d.size
+        bad += int((d != 0).sum())
+    print("8K real-dct mismatches: %d of %d (%.5f %%)" % (bad, total, 100.0 * bad / total))
+    assert bad <= 1e-4 * total
+    p_gpu, p_ref = _psnr(data, rows, w, h), _psnr(ref.file_bytes(), rows, w, h)
+    print("PSNR device %.4f dB, oracle %.4f dB" % (p_gpu, p_ref))
+    assert abs(p_gpu - p_ref) < 0.01
+    # the strict variant reproduces the oracle's file byte for byte at this size too
+    strict = J.Encoder((4, 2, 0), "real-dct-strict")
+    assert strict.encode_file_bytes(rows, w, h) == ref.file_bytes()
+
+
+def test_config_batch_1920x1080_422(J, oracle):
+    """A batch of independent images through one context, asynchronously; a sample is checked byte for byte."""
+    import torch
+    w, h, n = 1920, 1080, 16
+    enc = J.Encoder((4, 2, 2), "bin-dct")
+    imgs = [J.host.synth_bgr(w, h, seed=(4 << 32) | i) for i in range(n)]
+    dev = [torch.from_numpy(r).cuda() for r in imgs]
+    torch.cuda.synchronize()
+    for i in range(n):
+        enc.encode_device_async(dev[i].data_ptr(), w, h, imgs[i].shape[1], True)
+        nbits, ln = enc.finish()
+        if i % 5 == 0:
+            ref = oracle.RefImage.from_bgr(imgs[i], w, h, imgs[i].shape[1], (4, 2, 2), oracle.BIN).encode(threads=3)
+            assert nbits == ref.bits()[1]
+            np.testing.assert_array_equal(enc.scan(ln), ref.stuffed_scan())
+
+
+def test_config_gigapixel_stripes(J):
+    """32768x32768, 4:2:0, bin-dct: eight stripes stitched == the image coded whole on one GPU, and
+    un-stuffing the scan gives back the dense stream (no oracle run at this size)."""
+    S = J.stripes
+    tile = J.host.synth_bgr(8192, 4096, seed=(5 << 32))[:, :3 * 8192]
+    rows = np.tile(tile, (8, 4))                                  # 32768 rows of 98304 bytes
+    w = h = 32768
+    assert rows.shape == (h, 3 * w)
+    enc = J.Encoder((4, 2, 0), "bin-dct")
+    whole = enc.encode_scan(rows, w, h)
+    ff = np.nonzero(whole == 0xff)[0]
+    assert (whole[ff + 1] == 0).all()
+    enc.close()
+    n = 8
+    be = J.Encoder((4, 2, 0), "bin-dct")                          # one context takes the stripes in turn
+    plan = S.plan_stripes(h, 2, n)
+    dcs, codes, pieces = [], [], []
+    # phase by phase needs the stripe's coefficients to persist, so keep one context per stripe but
+    # free each after its piece is out: transform+code first (cheap to repeat), place last
+    jobs = [S.StripeJob(J.Encoder((4, 2, 0), "bin-dct"), k, n, rows, w, h, rows.shape[1], 2) for k in range(n)]
+    dcs = [j.transform() for j in jobs]
+    codes = [j.code(dcs) for j in jobs]
+    pieces = [j.place(codes) for j in jobs]
+    got = np.concatenate(pieces)
+    assert got.size == whole.size and np.array_equal(got, whole)
+    assert plan[0] == (0, 4096)
+    be.close()
