@@ -2,6 +2,7 @@
 // management around the kernels of front.hip, staged.hip and entropy.hip.
 #include "../../include/jpeg_hip.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -125,6 +126,10 @@ extern "C" int jpg_create(jpg_ctx **out, int device, int dct_algo, int ra, int r
               hipMalloc((void **)&c->d_dc, 4 * sizeof(int16_t)) == hipSuccess &&
               hipMalloc((void **)&c->eb.status, sizeof(DevStatus)) == hipSuccess &&
               hipMemset(c->eb.status, 0, sizeof(DevStatus)) == hipSuccess;
+#ifdef JPG_TRACE
+    if (ok) ok = hipMalloc((void **)&c->eb.trace, 4096 * 8 * sizeof(unsigned long long)) == hipSuccess &&
+                 hipMemset(c->eb.trace, 0, 4096 * 8 * sizeof(unsigned long long)) == hipSuccess;
+#endif
     if (ok) {
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
@@ -466,6 +471,19 @@ extern "C" int jpg_finish(jpg_ctx *c, uint64_t *nbits, size_t *stuffed_len) {
     if (int e = use_device(c)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->pending = false;
+#ifdef JPG_TRACE
+    if (c->eb.trace && getenv("JPG_TRACE_PRINT")) {
+        static unsigned long long h[4096 * 8];
+        (void)hipMemcpy(h, c->eb.trace, sizeof h, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < 512; b++) if (h[b * 8] && h[b * 8] < t0) t0 = h[b * 8];
+        for (int b : {0, 1, 100, 200, 300, 395, 400, 511}) {
+            fprintf(stderr, "wg %3d:", b);
+            for (int k = 0; k < 8; k++) fprintf(stderr, " %6.2f", h[b * 8 + k] ? (double)(h[b * 8 + k] - t0) / 100.0 : -1.0);
+            fprintf(stderr, " us\n");
+        }
+    }
+#endif
     if (int ke = kernel_error(c)) return ke;
     c->nbits = c->h_status->nbits;
     c->scan_len = (size_t)c->h_status->scan_bytes;

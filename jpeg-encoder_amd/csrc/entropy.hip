@@ -432,29 +432,56 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
 
 // The same prefix for an early item (i < DIRECT_ITEMS): the values of all items before it are
 // fetched in one go, so the item does not wait for a group sum that itself had to wait.
+// The caller publishes agg[i] from ANOTHER wave: loads and stores of a wave complete in issue
+// order, so a wave that stored first would have to see its store acknowledged (about 2 us across
+// XCDs) before it could look at the words it loaded.
 constexpr int DIRECT_ITEMS = 1024;
+#ifdef JPG_TRACE
+__device__ unsigned long long g_sub[4];
+#define JPG_SUB(K) do { if (blockIdx.x == 0) g_sub[K] = wall_clock64(); } while (0)
+#else
+#define JPG_SUB(K) do { } while (0)
+#endif
 __device__ __forceinline__ uint64_t sums_prefix_direct(const Sums &s, long long i, uint64_t own, int lane, bool &timeout) {
     constexpr int ROUNDS = DIRECT_ITEMS / 64;
     const int nr = (int)((i + 63) >> 6), g = (int)(i >> 6);
     uint64_t w[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) w[r] = (r < nr && r * 64 + lane < i) ? hw_load(&s.agg[r * 64 + lane]) : 0;
+    JPG_SUB(0);
+    // poll every word that is not valid yet, all of them per turn (one round trip per turn)
+    for (uint32_t spin = 0;; spin++) {
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++)
+            if (r < nr && r * 64 + lane < i && !hw_valid(w[r], s.epoch)) ok = false;
+        if (__ballot(!ok) == 0) break;
+        if (spin >= SPIN_LIMIT) { timeout = true; break; }
+        if (spin) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++)
+            if (r < nr && r * 64 + lane < i && !hw_valid(w[r], s.epoch)) w[r] = hw_load(&s.agg[r * 64 + lane]);
+    }
+    JPG_SUB(1);
     uint64_t all = 0, mine = 0;
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
-        if (r < nr) {
-            const uint64_t v = hw_wait(&s.agg[r * 64 + lane], r * 64 + lane < i, w[r], s.epoch, timeout);
+        if (r < nr && r * 64 + lane < i && hw_valid(w[r], s.epoch)) {
+            const uint64_t v = hw_value(w[r]);
             all += v;
             if (r == g) mine = v;
         }
     }
-    all = wave_sum64(all);
+    JPG_SUB(2);
+    // an item's value is at most STUFF_SEG here and there are fewer than DIRECT_ITEMS of them: 32 bits do
+    all = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan((uint32_t)all), 63);
     const bool closes_group = (i & 63) == 63 || i == s.n - 1;
     if (closes_group) {
-        const uint64_t gv = wave_sum64(mine) + own;
+        const uint64_t gv = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan((uint32_t)mine), 63) + own;
         if (lane == 0) hw_store(&s.grp[g], hw_pack(s.epoch, gv));
         if (i == s.n - 1 && lane == 0) hw_store(&s.hyp[0], hw_pack(s.epoch, all + own));
     }
+    JPG_SUB(3);
     return all;
 }
 
@@ -474,6 +501,7 @@ struct StreamArgs {
     uint32_t err_epoch;      // epoch errors are tagged with (that of the entropy launch)
     uint8_t *out;            // stuffed bytes, or the dense stream for k_stream<false>
     DevStatus *host_status;  // pinned host copy, filled at the end (may be null)
+    unsigned long long *trace;  // debug builds only
 };
 
 // number of 0xFF bytes in a word
@@ -502,13 +530,31 @@ __device__ __forceinline__ int find_last_le(const int *T, int r) {
     return lo;
 }
 
+// Workgroup barrier that orders LDS accesses only.  __syncthreads() also waits for every global
+// store of the wave to be acknowledged (about 2 us for a store that has to reach the other XCDs);
+// inside k_stream the barriers only guard LDS, and data loaded from global memory is waited for
+// where it is used.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#ifdef JPG_TRACE
+// debug build: wall-clock stamps (100 MHz) of the phases of the first pass of every workgroup
+// (kept in registers and stored at the end of the first pass, so that the stores do not perturb the phases)
+#define JPG_STAMP(K) do { stamps[K] = wall_clock64(); if ((K) == 7 && threadIdx.x == 0 && a.trace && !stamped) { \
+        for (int k_ = 0; k_ < 8; k_++) a.trace[blockIdx.x * 8 + k_] = stamps[k_]; \
+        if (blockIdx.x == 0) for (int k_ = 0; k_ < 4; k_++) a.trace[400 * 8 + k_] = g_sub[k_]; stamped = true; } } while (0)
+#else
+#define JPG_STAMP(K) do { } while (0)
+#endif
+
 // STUFF: byte stuffing of the (shifted) stream into a.out, a workgroup per segment of
 // STUFF_SEG stream bytes (blockIdx.x, + gridDim.x, ...).  !STUFF: the stream itself, dense.
 // Dynamic LDS: (ngroups + 1) 64-bit prefix sums of the chunk lengths per group.
 template <bool STUFF>
 __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
     extern __shared__ uint64_t sG[];     // [ngroups + 1] bits before each group of 64 chunks
-    __shared__ uint64_t sPart[256];
+    __shared__ uint64_t sPart[4];
     __shared__ int sT[TABLE + 1];          // chunk offsets relative to the segment's first bit
     __shared__ int sW[TABLE + 1];          // running count of the words wanted from each chunk
     __shared__ int sW0[TABLE];             // first word wanted from each chunk
@@ -516,6 +562,10 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
     __shared__ uint32_t s[4];
     __shared__ uint64_t sBefore;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef JPG_TRACE
+    unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool stamped = false;
+#endif
 
     // ---- bits per group, then their running sums
     {
@@ -535,28 +585,28 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
             sG[g] = sum;
         }
     }
-    __syncthreads();
+    lds_barrier();
+        JPG_STAMP(0);
     const int per = (a.ngroups + 255) / 256;
     const int lo = min(tid * per, a.ngroups), hi = min(lo + per, a.ngroups);
     uint64_t loc = 0;
     for (int g = lo; g < hi; g++) loc += sG[g];
-    sPart[tid] = loc;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const uint64_t v = tid >= d ? sPart[tid - d] : 0;
-        __syncthreads();
-        sPart[tid] += v;
-        __syncthreads();
-    }
-    uint64_t run = sPart[tid] - loc;
+    // inclusive scan of the 256 partial sums (each < 2^28) as two 32-bit wave scans: low 16 bits, rest
+    const uint32_t slo = wave_incl_scan((uint32_t)loc & 0xffffu), shi = wave_incl_scan((uint32_t)(loc >> 16));
+    if (lane == 63) sPart[wave] = ((uint64_t)shi << 16) + slo;
+    lds_barrier();
+    uint64_t incl = ((uint64_t)shi << 16) + slo;
+    for (int w = 0; w < wave; w++) incl += sPart[w];
+    const uint64_t nbits = sPart[0] + sPart[1] + sPart[2] + sPart[3];
+    uint64_t run = incl - loc;
     for (int g = lo; g < hi; g++) {
         const uint64_t v = sG[g];
         sG[g] = run;
         run += v;
     }
-    const uint64_t nbits = sPart[255];
     if (tid == 0) sG[a.ngroups] = nbits;
-    __syncthreads();
+    lds_barrier();
+        JPG_STAMP(1);
 
     const uint64_t tbits = nbits + a.shift;
     const uint64_t nbytes = (STUFF && !a.is_last) ? tbits >> 3 : (tbits + 7) >> 3;
@@ -581,13 +631,14 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
         const uint32_t v = cbase + tid < a.nchunks ? a.clen[cbase + tid] : 0u;
         const uint32_t vs = wave_incl_scan(v);
         if (lane == 63) s[wave] = vs;
-        __syncthreads();
+        lds_barrier();
         uint32_t ex = vs - v;
         for (int w = 0; w < wave; w++) ex += s[w];
         const long long rel0 = (long long)sG[g0] - P0;
         sT[tid] = (int)(rel0 + ex);
         if (tid == 255) sT[256] = (int)(rel0 + ex + v);
-        __syncthreads();
+        lds_barrier();
+        JPG_STAMP(2);
 
         // ---- gather: every word of a chunk slot that overlaps the segment is OR-ed into place
         const uint32_t *slots = a.sparse + (size_t)cbase * CHUNK_STRIDE_WORDS;
@@ -596,17 +647,18 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
             const int b0 = max(0, -Ti), b1 = min(L, DENSE_WORDS * 32 - Ti);   // bits of the chunk inside the window
             const int w0 = b0 >> 5, n = b1 > b0 ? ((b1 + 31) >> 5) - w0 : 0;
             sW0[tid] = w0;
-            __syncthreads();                                       // s[] is reused
+            lds_barrier();                                       // s[] is reused
             const uint32_t ns = wave_incl_scan((uint32_t)n);
             if (lane == 63) s[wave] = ns;
-            __syncthreads();
+            lds_barrier();
             uint32_t nex = ns - n;
             for (int w = 0; w < wave; w++) nex += s[w];
             sW[tid] = (int)nex;
             if (tid == 255) sW[256] = (int)(nex + n);
         }
         for (int k = tid; k < DENSE_WORDS; k += 256) sD[k] = 0;
-        __syncthreads();
+        lds_barrier();
+        JPG_STAMP(3);
         {
             // thread t takes wanted words t * rounds .. t * rounds + rounds - 1: one search, then a walk
             const int nwant = sW[256];
@@ -636,7 +688,8 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        JPG_STAMP(4);
 
         // ---- this thread's 16 bytes
         const uint64_t q = seg * (STUFF_SEG / 16) + tid;
@@ -666,23 +719,25 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
                 a.status->nbits = nbits;
                 if (a.host_status) *a.host_status = *a.status;
             }
-            __syncthreads();
+            lds_barrier();
             continue;
         }
         const uint32_t c = count_ff(t[0]) + count_ff(t[1]) + count_ff(t[2]) + count_ff(t[3]);
-        __syncthreads();                                           // s[] is reused
+        lds_barrier();                                           // s[] is reused
         const uint32_t sc = wave_incl_scan(c);
         if (lane == 63) s[wave] = sc;
-        __syncthreads();
+        lds_barrier();
+        JPG_STAMP(5);
         const uint32_t total = s[0] + s[1] + s[2] + s[3];
+        if (wave == 1 && lane == 0 && nseg && seg < DIRECT_ITEMS) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
         if (wave == 0) {
             bool timeout = false;
             uint64_t before = 0;
             if (nseg) {
-                if (lane == 0) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
                 if (seg < DIRECT_ITEMS) {
                     before = sums_prefix_direct(sums, (long long)seg, total, lane, timeout);
                 } else {
+                    if (lane == 0) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
                     const Probe probe = sums_probe(sums, (long long)seg, lane);
                     before = sums_prefix(sums, (long long)seg, total, probe, lane, timeout);
                 }
@@ -705,7 +760,8 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        JPG_STAMP(6);
         uint32_t before = sc - c;
         for (int w = 0; w < wave; w++) before += s[w];
         uint8_t *o = a.out + seg * STUFF_SEG + sBefore + 16 * tid + before;
@@ -724,7 +780,8 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        JPG_STAMP(7);
     }
 }
 
@@ -753,7 +810,7 @@ hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred
 
 static StreamArgs stream_args(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, uint8_t *out) {
     return StreamArgs{b.sparse, b.clen, b.nchunks, (int)((b.nchunks + 63) / 64), b.status, (uint32_t)(bit_offset & 7),
-                      head_bits, is_last, b.sagg, b.sgrp, b.shyp, b.stuff_epoch, b.epoch, out, b.host_status};
+                      head_bits, is_last, b.sagg, b.sgrp, b.shyp, b.stuff_epoch, b.epoch, out, b.host_status, b.trace};
 }
 
 template <bool STUFF>

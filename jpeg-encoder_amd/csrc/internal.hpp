@@ -69,6 +69,7 @@ struct EntropyBufs {
     uint8_t *scan;         // stuffed stream
     size_t scan_cap;
     size_t nseg_cap;
+    unsigned long long *trace;  // debug builds only (JPG_TRACE): phase stamps of the stream kernel
 };
 
 hipError_t launch_front(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s);
