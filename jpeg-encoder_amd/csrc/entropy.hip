@@ -430,61 +430,6 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     }
 }
 
-// The same prefix for an early item (i < DIRECT_ITEMS): the values of all items before it are
-// fetched in one go, so the item does not wait for a group sum that itself had to wait.
-// The caller publishes agg[i] from ANOTHER wave: loads and stores of a wave complete in issue
-// order, so a wave that stored first would have to see its store acknowledged (about 2 us across
-// XCDs) before it could look at the words it loaded.
-constexpr int DIRECT_ITEMS = 1024;
-#ifdef JPG_TRACE
-__device__ unsigned long long g_sub[4];
-#define JPG_SUB(K) do { if (blockIdx.x == 0) g_sub[K] = wall_clock64(); } while (0)
-#else
-#define JPG_SUB(K) do { } while (0)
-#endif
-__device__ __forceinline__ uint64_t sums_prefix_direct(const Sums &s, long long i, uint64_t own, int lane, bool &timeout) {
-    constexpr int ROUNDS = DIRECT_ITEMS / 64;
-    const int nr = (int)((i + 63) >> 6), g = (int)(i >> 6);
-    uint64_t w[ROUNDS];
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++) w[r] = (r < nr && r * 64 + lane < i) ? hw_load(&s.agg[r * 64 + lane]) : 0;
-    JPG_SUB(0);
-    // poll every word that is not valid yet, all of them per turn (one round trip per turn)
-    for (uint32_t spin = 0;; spin++) {
-        bool ok = true;
-#pragma unroll
-        for (int r = 0; r < ROUNDS; r++)
-            if (r < nr && r * 64 + lane < i && !hw_valid(w[r], s.epoch)) ok = false;
-        if (__ballot(!ok) == 0) break;
-        if (spin >= SPIN_LIMIT) { timeout = true; break; }
-        if (spin) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-        for (int r = 0; r < ROUNDS; r++)
-            if (r < nr && r * 64 + lane < i && !hw_valid(w[r], s.epoch)) w[r] = hw_load(&s.agg[r * 64 + lane]);
-    }
-    JPG_SUB(1);
-    uint64_t all = 0, mine = 0;
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        if (r < nr && r * 64 + lane < i && hw_valid(w[r], s.epoch)) {
-            const uint64_t v = hw_value(w[r]);
-            all += v;
-            if (r == g) mine = v;
-        }
-    }
-    JPG_SUB(2);
-    // an item's value is at most STUFF_SEG here and there are fewer than DIRECT_ITEMS of them: 32 bits do
-    all = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan((uint32_t)all), 63);
-    const bool closes_group = (i & 63) == 63 || i == s.n - 1;
-    if (closes_group) {
-        const uint64_t gv = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan((uint32_t)mine), 63) + own;
-        if (lane == 0) hw_store(&s.grp[g], hw_pack(s.epoch, gv));
-        if (i == s.n - 1 && lane == 0) hw_store(&s.hyp[0], hw_pack(s.epoch, all + own));
-    }
-    JPG_SUB(3);
-    return all;
-}
-
 // ---------------------------------------------------------------- stream readers
 
 struct StreamArgs {
@@ -518,7 +463,6 @@ constexpr int SEG_WORDS = SEG_BITS / 32;
 constexpr int DENSE_WORDS = SEG_WORDS + 2;   // the segment, plus the byte after it (tail of a stripe)
 // words a segment can need from the chunk slots: its own, plus a partial one at either end of each
 // of the at most 130 chunks under it (a full chunk has at least 64 x 4 bits)
-constexpr int GATHER_ROUNDS = (DENSE_WORDS + 2 * 132 + 255) / 256;
 
 // index of the last entry <= r in the ascending table T[0..TABLE], or -1 if there is none
 __device__ __forceinline__ int find_last_le(const int *T, int r) {
@@ -542,24 +486,35 @@ __device__ __forceinline__ void lds_barrier() {
 // debug build: wall-clock stamps (100 MHz) of the phases of the first pass of every workgroup
 // (kept in registers and stored at the end of the first pass, so that the stores do not perturb the phases)
 #define JPG_STAMP(K) do { stamps[K] = wall_clock64(); if ((K) == 7 && threadIdx.x == 0 && a.trace && !stamped) { \
-        for (int k_ = 0; k_ < 8; k_++) a.trace[blockIdx.x * 8 + k_] = stamps[k_]; \
-        if (blockIdx.x == 0) for (int k_ = 0; k_ < 4; k_++) a.trace[400 * 8 + k_] = g_sub[k_]; stamped = true; } } while (0)
+        for (int k_ = 0; k_ < 8; k_++) a.trace[blockIdx.x * 8 + k_] = stamps[k_]; stamped = true; } } while (0)
 #else
 #define JPG_STAMP(K) do { } while (0)
 #endif
 
+#ifndef JPG_ST_THREADS
+#define JPG_ST_THREADS 512
+#endif
+constexpr int ST_THREADS = JPG_ST_THREADS;    // threads per segment
+constexpr int ST_WAVES = ST_THREADS / 64;
+constexpr int WPT = SEG_WORDS / ST_THREADS;   // 32-bit words of the segment per thread
+constexpr int DIRECT_ITEMS = ST_THREADS;      // segments whose predecessors' counts are read directly, one per thread
+constexpr int GATHER_ROUNDS = (DENSE_WORDS + 2 * 132 + ST_THREADS - 1) / ST_THREADS;
+static_assert(SEG_WORDS == WPT * ST_THREADS && ST_THREADS >= TABLE, "whole words per thread");
+
 // STUFF: byte stuffing of the (shifted) stream into a.out, a workgroup per segment of
 // STUFF_SEG stream bytes (blockIdx.x, + gridDim.x, ...).  !STUFF: the stream itself, dense.
 // Dynamic LDS: (ngroups + 1) 64-bit prefix sums of the chunk lengths per group.
+// The kernel is a chain of short dependent steps; 16 waves per workgroup keep the per-thread
+// instruction count of every step small (a lone wave issues an instruction only every ~5 ns).
 template <bool STUFF>
-__global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
+__global__ __launch_bounds__(ST_THREADS) void k_stream(StreamArgs a) {
     extern __shared__ uint64_t sG[];     // [ngroups + 1] bits before each group of 64 chunks
-    __shared__ uint64_t sPart[4];
+    __shared__ uint64_t sPart[ST_WAVES];
     __shared__ int sT[TABLE + 1];          // chunk offsets relative to the segment's first bit
     __shared__ int sW[TABLE + 1];          // running count of the words wanted from each chunk
     __shared__ int sW0[TABLE];             // first word wanted from each chunk
     __shared__ uint32_t sD[DENSE_WORDS];   // the segment's bits in place
-    __shared__ uint32_t s[4];
+    __shared__ uint32_t s[ST_WAVES];
     __shared__ uint64_t sBefore;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef JPG_TRACE
@@ -568,36 +523,42 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
 #endif
 
     // ---- bits per group, then their running sums
-    {
-        for (int g = tid; g < a.ngroups; g += 256) {
-            const long long c0 = (long long)g * 64;
-            uint32_t sum = 0;
-            if (c0 + 64 <= a.nchunks) {
-                const uint4 *p = reinterpret_cast<const uint4 *>(a.clen + c0);
-                uint4 v[16];
+    for (int g = tid; g < a.ngroups; g += ST_THREADS) {
+        const long long c0 = (long long)g * 64;
+        uint32_t sum = 0;
+        if (c0 + 64 <= a.nchunks) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.clen + c0);
+            uint4 v[8];                                          // two batches: the kernel has to stay within 64 registers
 #pragma unroll
-                for (int k = 0; k < 16; k++) v[k] = p[k];
+            for (int k = 0; k < 8; k++) v[k] = p[k];
 #pragma unroll
-                for (int k = 0; k < 16; k++) sum += v[k].x + v[k].y + v[k].z + v[k].w;
-            } else {
-                for (long long c = c0; c < a.nchunks; c++) sum += a.clen[c];
-            }
-            sG[g] = sum;
+            for (int k = 0; k < 8; k++) sum += v[k].x + v[k].y + v[k].z + v[k].w;
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = p[8 + k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) sum += v[k].x + v[k].y + v[k].z + v[k].w;
+        } else {
+            for (long long c = c0; c < a.nchunks; c++) sum += a.clen[c];
         }
+        sG[g] = sum;
     }
     lds_barrier();
-        JPG_STAMP(0);
-    const int per = (a.ngroups + 255) / 256;
+    JPG_STAMP(0);
+    const int per = (a.ngroups + ST_THREADS - 1) / ST_THREADS;
     const int lo = min(tid * per, a.ngroups), hi = min(lo + per, a.ngroups);
     uint64_t loc = 0;
     for (int g = lo; g < hi; g++) loc += sG[g];
-    // inclusive scan of the 256 partial sums (each < 2^28) as two 32-bit wave scans: low 16 bits, rest
+    // inclusive scan of the partial sums (each < 2^26) as two 32-bit wave scans: low 16 bits, rest
     const uint32_t slo = wave_incl_scan((uint32_t)loc & 0xffffu), shi = wave_incl_scan((uint32_t)(loc >> 16));
     if (lane == 63) sPart[wave] = ((uint64_t)shi << 16) + slo;
     lds_barrier();
-    uint64_t incl = ((uint64_t)shi << 16) + slo;
-    for (int w = 0; w < wave; w++) incl += sPart[w];
-    const uint64_t nbits = sPart[0] + sPart[1] + sPart[2] + sPart[3];
+    uint64_t incl = ((uint64_t)shi << 16) + slo, nbits = 0;
+#pragma unroll
+    for (int w = 0; w < ST_WAVES; w++) {
+        const uint64_t p = sPart[w];
+        if (w < wave) incl += p;
+        nbits += p;
+    }
     uint64_t run = incl - loc;
     for (int g = lo; g < hi; g++) {
         const uint64_t v = sG[g];
@@ -606,7 +567,7 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
     }
     if (tid == 0) sG[a.ngroups] = nbits;
     lds_barrier();
-        JPG_STAMP(1);
+    JPG_STAMP(1);
 
     const uint64_t tbits = nbits + a.shift;
     const uint64_t nbytes = (STUFF && !a.is_last) ? tbits >> 3 : (tbits + 7) >> 3;
@@ -615,7 +576,7 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
     const Sums sums{a.agg, a.grp, a.hyp, a.epoch, (long long)nseg};
 
     for (uint64_t seg = blockIdx.x; seg < nloop; seg += gridDim.x) {
-        // ---- offsets of the chunks under this segment
+        // ---- offsets of the chunks under this segment (first TABLE threads)
         const long long P0 = (long long)seg * SEG_BITS - (long long)a.shift;   // stream position of the segment's first bit
         const uint64_t p0 = P0 > 0 ? (uint64_t)P0 : 0;
         int g0 = 0;
@@ -628,41 +589,48 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
             g0 = l;
         }
         const long long cbase = (long long)g0 * 64;
-        const uint32_t v = cbase + tid < a.nchunks ? a.clen[cbase + tid] : 0u;
+        const uint32_t v = (tid < TABLE && cbase + tid < a.nchunks) ? a.clen[cbase + tid] : 0u;
         const uint32_t vs = wave_incl_scan(v);
         if (lane == 63) s[wave] = vs;
         lds_barrier();
-        uint32_t ex = vs - v;
-        for (int w = 0; w < wave; w++) ex += s[w];
-        const long long rel0 = (long long)sG[g0] - P0;
-        sT[tid] = (int)(rel0 + ex);
-        if (tid == 255) sT[256] = (int)(rel0 + ex + v);
+        if (tid < TABLE) {
+            uint32_t ex = vs - v;
+            for (int w = 0; w < wave; w++) ex += s[w];
+            const long long rel0 = (long long)sG[g0] - P0;
+            sT[tid] = (int)(rel0 + ex);
+            if (tid == TABLE - 1) sT[TABLE] = (int)(rel0 + ex + v);
+        }
         lds_barrier();
         JPG_STAMP(2);
 
         // ---- gather: every word of a chunk slot that overlaps the segment is OR-ed into place
         const uint32_t *slots = a.sparse + (size_t)cbase * CHUNK_STRIDE_WORDS;
         {
-            const int Ti = sT[tid], L = sT[tid + 1] - Ti;
-            const int b0 = max(0, -Ti), b1 = min(L, DENSE_WORDS * 32 - Ti);   // bits of the chunk inside the window
-            const int w0 = b0 >> 5, n = b1 > b0 ? ((b1 + 31) >> 5) - w0 : 0;
-            sW0[tid] = w0;
-            lds_barrier();                                       // s[] is reused
+            int n = 0;
+            if (tid < TABLE) {
+                const int Ti = sT[tid], L = sT[tid + 1] - Ti;
+                const int b0 = max(0, -Ti), b1 = min(L, DENSE_WORDS * 32 - Ti);   // bits of the chunk inside the window
+                const int w0 = b0 >> 5;
+                n = b1 > b0 ? ((b1 + 31) >> 5) - w0 : 0;
+                sW0[tid] = w0;
+            }
             const uint32_t ns = wave_incl_scan((uint32_t)n);
-            if (lane == 63) s[wave] = ns;
+            if (lane == 63) s[wave] = ns;                        // (every thread read s[] before the last barrier)
             lds_barrier();
-            uint32_t nex = ns - n;
-            for (int w = 0; w < wave; w++) nex += s[w];
-            sW[tid] = (int)nex;
-            if (tid == 255) sW[256] = (int)(nex + n);
+            if (tid < TABLE) {
+                uint32_t nex = ns - n;
+                for (int w = 0; w < wave; w++) nex += s[w];
+                sW[tid] = (int)nex;
+                if (tid == TABLE - 1) sW[TABLE] = (int)(nex + n);
+            }
         }
-        for (int k = tid; k < DENSE_WORDS; k += 256) sD[k] = 0;
+        for (int k = tid; k < DENSE_WORDS; k += ST_THREADS) sD[k] = 0;
         lds_barrier();
         JPG_STAMP(3);
         {
             // thread t takes wanted words t * rounds .. t * rounds + rounds - 1: one search, then a walk
-            const int nwant = sW[256];
-            const int rounds = (nwant + 255) >> 8;                // <= GATHER_ROUNDS
+            const int nwant = sW[TABLE];
+            const int rounds = (nwant + ST_THREADS - 1) / ST_THREADS;   // <= GATHER_ROUNDS
             uint32_t wv[GATHER_ROUNDS];
             int pos[GATHER_ROUNDS];
             int f = tid * rounds;
@@ -691,30 +659,24 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
         lds_barrier();
         JPG_STAMP(4);
 
-        // ---- this thread's 16 bytes
-        const uint64_t q = seg * (STUFF_SEG / 16) + tid;
-        uint32_t t[4] = {0, 0, 0, 0};
-        if (16 * q < nbytes) {
+        // ---- this thread's WPT words
+        const uint64_t q = seg * SEG_WORDS + (uint64_t)WPT * tid;  // first word of the stream
+        uint32_t t[WPT];
 #pragma unroll
-            for (int k = 0; k < 4; k++) t[k] = sD[4 * tid + k];
-            if (q == 0 && a.shift) t[0] |= a.head << 24;
-            // a stripe that is not the last one ends at a byte boundary: drop what follows
-            const uint64_t rem = nbytes - 16 * q;
-            if (rem < 16) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const long long keep = (long long)rem - 4 * k;   // bytes of word k inside the stream
-                    if (keep <= 0) t[k] = 0;
-                    else if (keep < 4) t[k] &= ~0u << (32 - 8 * (int)keep);
-                }
+        for (int k = 0; k < WPT; k++) {
+            t[k] = 0;
+            if (4 * (q + k) < nbytes) {
+                t[k] = sD[WPT * tid + k];
+                if (q + k == 0 && a.shift) t[k] |= a.head << 24;
+                // a stripe that is not the last one ends at a byte boundary: drop what follows
+                const uint64_t rem = nbytes - 4 * (q + k);
+                if (rem < 4) t[k] &= ~0u << (32 - 8 * (int)rem);
             }
         }
         if (!STUFF) {
-            if (16 * q < nbytes) {
-                uint4 o = make_uint4(__builtin_bswap32(t[0]), __builtin_bswap32(t[1]), __builtin_bswap32(t[2]),
-                                     __builtin_bswap32(t[3]));
-                reinterpret_cast<uint4 *>(a.out)[q] = o;           // the buffer is padded to 16 bytes
-            }
+#pragma unroll
+            for (int k = 0; k < WPT; k++)
+                if (4 * (q + k) < nbytes) reinterpret_cast<uint32_t *>(a.out)[q + k] = __builtin_bswap32(t[k]);   // padded buffer
             if (seg == nloop - 1 && tid == 0) {
                 a.status->nbits = nbits;
                 if (a.host_status) *a.host_status = *a.status;
@@ -722,58 +684,75 @@ __global__ __launch_bounds__(256) void k_stream(StreamArgs a) {
             lds_barrier();
             continue;
         }
-        const uint32_t c = count_ff(t[0]) + count_ff(t[1]) + count_ff(t[2]) + count_ff(t[3]);
-        lds_barrier();                                           // s[] is reused
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < WPT; k++) c += count_ff(t[k]);
         const uint32_t sc = wave_incl_scan(c);
-        if (lane == 63) s[wave] = sc;
+        if (lane == 63) s[wave] = sc;                            // (s[] was last read before the previous barrier)
         lds_barrier();
         JPG_STAMP(5);
-        const uint32_t total = s[0] + s[1] + s[2] + s[3];
-        if (wave == 1 && lane == 0 && nseg && seg < DIRECT_ITEMS) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
-        if (wave == 0) {
-            bool timeout = false;
+        uint32_t total = 0, before_in_seg = sc - c;
+#pragma unroll
+        for (int w = 0; w < ST_WAVES; w++) {
+            const uint32_t p = s[w];
+            if (w < wave) before_in_seg += p;
+            total += p;
+        }
+        // ---- 0xFF bytes in the segments before this one
+        bool timeout = false;
+        if (nseg && seg < DIRECT_ITEMS) {
+            // every thread fetches the count of one earlier segment; the segment's own count is published by
+            // the last wave, which rarely has anything to fetch (loads and stores of a wave complete in
+            // issue order, so a wave that stored first would wait ~2 us for the acknowledgement)
+            if (tid == ST_THREADS - 1) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
+            const bool need = (uint64_t)tid < seg;
+            const uint64_t val = hw_wait(&a.agg[tid], need, need ? hw_load(&a.agg[tid]) : 0, a.epoch, timeout);
+            const uint32_t ws = wave_incl_scan((uint32_t)val);   // a count is at most STUFF_SEG, 1024 of them: 32 bits do
+            if (lane == 63) sPart[wave] = ws;
+            lds_barrier();
+            uint64_t before = 0;
+#pragma unroll
+            for (int w = 0; w < ST_WAVES; w++) before += sPart[w];
+            const int g = (int)(seg >> 6);
+            const bool closes_group = (seg & 63) == 63 || seg == nseg - 1;
+            if (closes_group && tid == 0) hw_store(&a.grp[g], hw_pack(a.epoch, sPart[g] + total));
+            if (seg == nseg - 1 && tid == 0) hw_store(&a.hyp[0], hw_pack(a.epoch, before + total));
+            if (tid == 0) sBefore = before;
+        } else if (wave == 0) {
             uint64_t before = 0;
             if (nseg) {
-                if (seg < DIRECT_ITEMS) {
-                    before = sums_prefix_direct(sums, (long long)seg, total, lane, timeout);
-                } else {
-                    if (lane == 0) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
-                    const Probe probe = sums_probe(sums, (long long)seg, lane);
-                    before = sums_prefix(sums, (long long)seg, total, probe, lane, timeout);
-                }
+                if (lane == 0) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
+                const Probe probe = sums_probe(sums, (long long)seg, lane);
+                before = sums_prefix(sums, (long long)seg, total, probe, lane, timeout);
             }
-            if (lane == 0) {
-                sBefore = before;
-                if (timeout) raise_error(a.status, a.err_epoch, JPG_ERR_HIP);
-                if (seg == nloop - 1) {
-                    a.status->nbits = nbits;
-                    a.status->scan_bytes = nbytes + before + total;
-                    // bits of the partial byte a non-final stripe leaves to its successor
-                    uint32_t tail = 0;
-                    if (!a.is_last && (tbits & 7)) {
-                        const int r = (int)(8 * nbytes - seg * SEG_BITS);
-                        tail = (sD[r >> 5] >> (24 - (r & 31))) & 0xffu;
-                        if (nbytes == 0) tail |= a.head;
-                    }
-                    a.status->tail = tail;
-                    if (a.host_status) *a.host_status = *a.status;
-                }
-            }
+            if (lane == 0) sBefore = before;
         }
+        if (__ballot(timeout) && lane == 0) raise_error(a.status, a.err_epoch, JPG_ERR_HIP);
         lds_barrier();
         JPG_STAMP(6);
-        uint32_t before = sc - c;
-        for (int w = 0; w < wave; w++) before += s[w];
-        uint8_t *o = a.out + seg * STUFF_SEG + sBefore + 16 * tid + before;
-        if (16 * q + 16 <= nbytes && c == 0 && ((reinterpret_cast<uintptr_t>(o) & 3) == 0)) {
-            // common case: 16 plain bytes, destination word-aligned
-            uint32_t *o4 = reinterpret_cast<uint32_t *>(o);
+        const uint64_t before_segs = sBefore;
+        if (seg == nloop - 1 && tid == 0) {
+            a.status->nbits = nbits;
+            a.status->scan_bytes = nbytes + before_segs + total;
+            // bits of the partial byte a non-final stripe leaves to its successor
+            uint32_t tail = 0;
+            if (!a.is_last && (tbits & 7)) {
+                const int r = (int)(8 * nbytes - seg * SEG_BITS);
+                tail = (sD[r >> 5] >> (24 - (r & 31))) & 0xffu;
+                if (nbytes == 0) tail |= a.head;
+            }
+            a.status->tail = tail;
+            if (a.host_status) *a.host_status = *a.status;
+        }
+        uint8_t *o = a.out + seg * STUFF_SEG + before_segs + 4 * WPT * tid + before_in_seg;
+        if (4 * (q + WPT) <= nbytes && c == 0 && ((reinterpret_cast<uintptr_t>(o) & 3) == 0)) {
+            // common case: plain bytes, destination word-aligned
 #pragma unroll
-            for (int k = 0; k < 4; k++) o4[k] = __builtin_bswap32(t[k]);
+            for (int k = 0; k < WPT; k++) reinterpret_cast<uint32_t *>(o)[k] = __builtin_bswap32(t[k]);
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if (16 * q + k < nbytes) {
+            for (int k = 0; k < 4 * WPT; k++) {
+                if (4 * q + k < nbytes) {
                     const uint8_t b = (uint8_t)(t[k >> 2] >> (24 - 8 * (k & 3)));
                     *o++ = b;
                     if (b == 0xff) *o++ = 0;
@@ -817,9 +796,25 @@ template <bool STUFF>
 static hipError_t launch_stream(const EntropyBufs &b, StreamArgs a, hipStream_t s) {
     if (a.ngroups > MAX_GROUPS || !a.out) return hipErrorInvalidValue;
     const size_t lds = (a.ngroups + 1) * sizeof(uint64_t);
-    const size_t cap = b.stuff_grid ? b.stuff_grid : 1024;
+    // no more workgroups than fit on the device at once: a segment waits for the segments before it, which
+    // must therefore be running or finished whatever the dispatch order
+    static long long resident_cache[2][64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    long long resident = dev >= 0 && dev < 64 ? resident_cache[STUFF][dev] : 0;
+    if (resident == 0) {
+        int cus = 0, per_cu = 0;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<STUFF>, ST_THREADS, lds);
+        if (e != hipSuccess) return e;
+        resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
+        if (dev >= 0 && dev < 64) resident_cache[STUFF][dev] = resident;
+    }
+    size_t cap = (size_t)resident;
+    if (b.stuff_grid && b.stuff_grid < cap) cap = b.stuff_grid;
     const unsigned grid = (unsigned)(b.nseg_cap < cap ? (b.nseg_cap ? b.nseg_cap : 1) : cap);
-    hipLaunchKernelGGL(k_stream<STUFF>, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k_stream<STUFF>, dim3(grid), dim3(ST_THREADS), lds, s, a);
     return hipGetLastError();
 }
 
