@@ -47,12 +47,21 @@ struct TileCfg {
 // 4 pixels of one row: 12 bytes B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3 -> packed Y, Cb, Cr bytes
 __device__ __forceinline__ void convert4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t &y4, uint32_t (&cb)[4],
                                          uint32_t (&cr)[4]) {
-    uint32_t y[4];
-    rgb_to_ycbcr((float)((d0 >> 16) & 0xff), (float)((d0 >> 8) & 0xff), (float)(d0 & 0xff), y[0], cb[0], cr[0]);
-    rgb_to_ycbcr((float)((d1 >> 8) & 0xff), (float)(d1 & 0xff), (float)(d0 >> 24), y[1], cb[1], cr[1]);
-    rgb_to_ycbcr((float)(d2 & 0xff), (float)(d1 >> 24), (float)((d1 >> 16) & 0xff), y[2], cb[2], cr[2]);
-    rgb_to_ycbcr((float)(d2 >> 24), (float)((d2 >> 16) & 0xff), (float)((d2 >> 8) & 0xff), y[3], cb[3], cr[3]);
-    y4 = y[0] | (y[1] << 8) | (y[2] << 16) | (y[3] << 24);
+    float fy[4], fb[4], fr[4];
+    rgb_to_ycbcr_f((float)((d0 >> 16) & 0xff), (float)((d0 >> 8) & 0xff), (float)(d0 & 0xff), fy[0], fb[0], fr[0]);
+    rgb_to_ycbcr_f((float)((d1 >> 8) & 0xff), (float)(d1 & 0xff), (float)(d0 >> 24), fy[1], fb[1], fr[1]);
+    rgb_to_ycbcr_f((float)(d2 & 0xff), (float)(d1 >> 24), (float)((d1 >> 16) & 0xff), fy[2], fb[2], fr[2]);
+    rgb_to_ycbcr_f((float)(d2 >> 24), (float)((d2 >> 16) & 0xff), (float)((d2 >> 8) & 0xff), fy[3], fb[3], fr[3]);
+    // `as u8` (truncation; nothing saturates): the four Y bytes are converted into place
+    cvt_pack8<0>(y4, fy[0]);
+    cvt_pack8<1>(y4, fy[1]);
+    cvt_pack8<2>(y4, fy[2]);
+    cvt_pack8<3>(y4, fy[3]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        cb[q] = (uint32_t)fb[q];
+        cr[q] = (uint32_t)fr[q];
+    }
 }
 
 template <int HS, int VS>

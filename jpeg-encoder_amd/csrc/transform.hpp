@@ -152,9 +152,70 @@ __device__ __forceinline__ void dct8(float a0, float a1, float a2, float a3, flo
         o[v] = fmaf(cosv(v, 3), d3, fmaf(cosv(v, 2), d2, fmaf(cosv(v, 1), d1, cosv(v, 0) * d0)));
 }
 
+// scale and quantiser of coefficient (u, v) as one factor
+template <bool CHROMA>
+__device__ __host__ constexpr float qfold(int u, int v) {
+    return dct_scale(u, v) / (float)quant<CHROMA>(u * 8 + v);
+}
+
+// Second (vertical) pass for column V with that factor folded into the constants of the last
+// operation of every output, so that o[u] is the quantised value before truncation.  o[0] is
+// left unscaled (its last operation is an addition; the DC coefficient takes the exact path).
+template <bool CHROMA, int V>
+__device__ __forceinline__ void dct8_quant(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7,
+                                           float (&o)[8]) {
+    const float s0 = a0 + a7, s1 = a1 + a6, s2 = a2 + a5, s3 = a3 + a4;
+    const float d0 = a0 - a7, d1 = a1 - a6, d2 = a2 - a5, d3 = a3 - a4;
+    const float ss0 = s0 + s3, ss1 = s1 + s2, sd0 = s0 - s3, sd1 = s1 - s2;
+    o[0] = ss0 + ss1;
+    o[4] = (cosv(4, 0) * qfold<CHROMA>(4, V)) * (ss0 - ss1);
+    o[2] = fmaf(cosv(2, 1) * qfold<CHROMA>(2, V), sd1, (cosv(2, 0) * qfold<CHROMA>(2, V)) * sd0);
+    o[6] = fmaf(cosv(6, 1) * qfold<CHROMA>(6, V), sd1, (cosv(6, 0) * qfold<CHROMA>(6, V)) * sd0);
+#pragma unroll
+    for (int u = 1; u < 8; u += 2) {
+        const float k = qfold<CHROMA>(u, V);
+        o[u] = fmaf(cosv(u, 3) * k, d3, fmaf(cosv(u, 2) * k, d2, fmaf(cosv(u, 1) * k, d1, (cosv(u, 0) * k) * d0)));
+    }
+}
+
+// f32 -> i32 (truncation, like `as i16` on an in-range value) written straight into one 16-bit half
+// of a dword: conversion and packing in one instruction.  `fresh`: the other half is not written yet.
+template <int HALF>
+__device__ __forceinline__ void cvt_pack16(uint32_t &d, float x, bool fresh) {
+    if (fresh) {
+        if (HALF) asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:DWORD" : "=v"(d) : "v"(x));
+        else asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD" : "=v"(d) : "v"(x));
+    } else {
+        if (HALF) asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(x));
+        else asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(x));
+    }
+}
+
+template <bool CHROMA, int V>
+__device__ __forceinline__ void column_real(const float (&t)[8][8], uint32_t (&w)[32], bool (&seen)[32]) {
+    float o[8];
+    dct8_quant<CHROMA, V>(t[0][V], t[1][V], t[2][V], t[3][V], t[4][V], t[5][V], t[6][V], t[7][V], o);
+    if (V == 0) {
+        // level shift (src/jpeg/dct_quant.rs:63-65): subtracting 128 from every sample moves only
+        // the DC sum, by exactly 64*128; then the reference's ((0.25*au*av*sum)/q) as i16
+        // (src/jpeg/dct_quant.rs:227-230)
+        const float s = dct_scale(0, 0) * (o[0] - 8192.0f);
+        o[0] = div_const(s, (float)quant<CHROMA>(0), rcp_rn(quant<CHROMA>(0)));
+    } else {
+        o[0] = o[0] * qfold<CHROMA>(0, V);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = jpgtab::ZZ_OF_NATURAL.k[u * 8 + V];
+        if (k & 1) cvt_pack16<1>(w[k >> 1], o[u], !seen[k >> 1]);
+        else cvt_pack16<0>(w[k >> 1], o[u], !seen[k >> 1]);
+        seen[k >> 1] = true;
+    }
+}
+
 template <bool CHROMA>
 __device__ __forceinline__ void transform_real(const uint32_t (&px)[16], uint32_t *slot) {
-    float t[8][8];  // t[x][v] = sum_y e[x][y] cos(v,y); the level shift is applied to the DC sum below
+    float t[8][8];  // t[x][v] = sum_y e[x][y] cos(v,y); the level shift is applied to the DC sum
 #pragma unroll
     for (int x = 0; x < 8; x++) {
         float e[8];
@@ -164,29 +225,14 @@ __device__ __forceinline__ void transform_real(const uint32_t (&px)[16], uint32_
     }
     uint32_t w[32];
     bool seen[32] = {};
-#pragma unroll
-    for (int v = 0; v < 8; v++) {
-        float o[8];
-        dct8(t[0][v], t[1][v], t[2][v], t[3][v], t[4][v], t[5][v], t[6][v], t[7][v], o);
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int n = u * 8 + v;
-            int r;
-            if (n == 0) {
-                // level shift (src/jpeg/dct_quant.rs:63-65): subtracting 128 from every
-                // sample moves only the DC sum, by exactly 64*128; then the
-                // reference's ((0.25*au*av*sum)/q) as i16 (src/jpeg/dct_quant.rs:227-230)
-                const float s = dct_scale(0, 0) * (o[0] - 8192.0f);
-                r = (int)div_const(s, (float)quant<CHROMA>(0), rcp_rn(quant<CHROMA>(0)));
-            } else {
-                // scale and quantiser folded into one factor
-                r = (int)(o[u] * (dct_scale(u, v) / (float)quant<CHROMA>(n)));
-            }
-            const int k = jpgtab::ZZ_OF_NATURAL.k[n];
-            put16_rt(w, k, r, !seen[k >> 1]);
-            seen[k >> 1] = true;
-        }
-    }
+    column_real<CHROMA, 0>(t, w, seen);
+    column_real<CHROMA, 1>(t, w, seen);
+    column_real<CHROMA, 2>(t, w, seen);
+    column_real<CHROMA, 3>(t, w, seen);
+    column_real<CHROMA, 4>(t, w, seen);
+    column_real<CHROMA, 5>(t, w, seen);
+    column_real<CHROMA, 6>(t, w, seen);
+    column_real<CHROMA, 7>(t, w, seen);
     store_packed(w, slot);
 }
 
@@ -290,19 +336,34 @@ __device__ __forceinline__ void transform_block(const uint32_t (&px)[16], uint32
 
 // BT.601 full-range conversion in the reference's f32 evaluation order
 // (src/utils/colorspace.rs:5-15), `as u8` = truncate toward zero and saturate.
-__device__ __forceinline__ void rgb_to_ycbcr(float r, float g, float b, uint32_t &y, uint32_t &cb, uint32_t &cr) {
-    float fy = 0.299f * r + 0.587f * g;
+__device__ __forceinline__ void rgb_to_ycbcr_f(float r, float g, float b, float &fy, float &fb, float &fr) {
+    fy = 0.299f * r + 0.587f * g;
     fy = fy + 0.114f * b;
-    float fb = 128.0f - 0.168736f * r;
+    fb = 128.0f - 0.168736f * r;
     fb = fb - 0.331264f * g;
     fb = fmaf(0.5f, b, fb);        // 0.5*b is exact, so one rounding either way
-    float fr = fmaf(0.5f, r, 128.0f);  // exact: k/2 + 128 is representable
+    fr = fmaf(0.5f, r, 128.0f);    // exact: k/2 + 128 is representable
     fr = fr - 0.418688f * g;
     fr = fr - 0.081312f * b;
+}
+
+__device__ __forceinline__ void rgb_to_ycbcr(float r, float g, float b, uint32_t &y, uint32_t &cb, uint32_t &cr) {
+    float fy, fb, fr;
+    rgb_to_ycbcr_f(r, g, b, fy, fb, fr);
     // `as u8`: truncation; the three values lie in [0, 256) for every input, so nothing saturates
     y = (uint32_t)fy;
     cb = (uint32_t)fb;
     cr = (uint32_t)fr;
+}
+
+// f32 -> u32 (truncation) written straight into byte N of a dword: conversion and packing in one
+// instruction; byte 0 starts the dword (the other bytes become 0).
+template <int N>
+__device__ __forceinline__ void cvt_pack8(uint32_t &d, float x) {
+    if (N == 0) asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD" : "=v"(d) : "v"(x));
+    else if (N == 1) asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(x));
+    else if (N == 2) asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(x));
+    else asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(x));
 }
 
 
