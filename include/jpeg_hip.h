@@ -108,6 +108,11 @@ int jpg_front_host(jpg_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t h
  * stream without any host synchronisation.  jpg_finish() waits and reports. */
 int jpg_encode_device_async(jpg_ctx *ctx, const uint8_t *dev_pixels, int32_t width, int32_t height,
                             uint32_t row_stride, int bottom_up);
+/* Page-locked host memory (release with jpg_free).  Rows handed to jpg_load_bgr,
+ * jpg_front_host or jpg_encode_scan from such memory are copied by DMA at full
+ * link speed; ordinary (pageable) memory is staged through the library's own
+ * page-locked buffers.  No counterpart in the reference. */
+void *jpg_host_alloc(size_t bytes);
 /* wait for the queued encode; nbits/stuffed_len may be NULL.  Returns the
  * reference's range errors (JPG_ERR_DC_RANGE/JPG_ERR_AC_RANGE) if a kernel
  * met a coefficient the Huffman tables cannot code. */

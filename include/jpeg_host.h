@@ -34,6 +34,11 @@ typedef struct jph_bmp {
  * reads do.  Release with jph_bmp_free. */
 int jph_bmp_read(const char *path, jph_bmp *out);
 void jph_bmp_free(jph_bmp *bmp);
+/* The same with the pixel array placed in memory from `alloc` (for example page-locked
+ * memory from jpg_host_alloc, which the device can read without a staging copy).
+ * `release` is only used if reading fails; afterwards the caller releases out->pixels
+ * itself, not with jph_bmp_free. */
+int jph_bmp_read_with(const char *path, jph_bmp *out, void *(*alloc)(size_t), void (*release)(void *));
 /* writes a 24-bit bottom-up BMP (54-byte header) from rows in file order */
 int jph_bmp_write(const char *path, int32_t width, int32_t height, const uint8_t *rows, uint32_t row_stride);
 

@@ -35,6 +35,9 @@ struct jpg_ctx {
     int16_t *d_dc = nullptr;     // last DCs out (3 values)
     EntropyBufs eb{};
     size_t ent_cap = 0;          // in blocks
+    // two page-locked bounce buffers for rows that arrive in pageable host memory
+    uint8_t *h_bounce[2] = {nullptr, nullptr};
+    hipEvent_t bounce_done[2] = {nullptr, nullptr};
     DevStatus *h_status = nullptr;  // pinned copy of eb.status
     int16_t *h_dc = nullptr;        // pinned
     uint64_t nbits = 0;
@@ -154,6 +157,10 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
                    c->eb.bits, c->eb.sagg, c->eb.sgrp, c->eb.shyp, c->eb.scan};
     for (void *p : dev)
         if (p) (void)hipFree(p);
+    for (int k = 0; k < 2; k++) {
+        if (c->h_bounce[k]) (void)hipHostFree(c->h_bounce[k]);
+        if (c->bounce_done[k]) (void)hipEventDestroy(c->bounce_done[k]);
+    }
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_dc) (void)hipHostFree(c->h_dc);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -240,6 +247,49 @@ static int ensure_dense(jpg_ctx *c) {
     return JPG_OK;
 }
 
+constexpr size_t BOUNCE_BYTES = 8u << 20;
+
+// is `p` host memory the device can read directly (page-locked or registered)?
+static bool is_pinned_host(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();   // an ordinary malloc pointer is reported as an error by some runtimes
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// pageable rows -> device, through the two bounce buffers: while one chunk travels by DMA the
+// next is packed by the CPU (a pageable hipMemcpy2D runs at a fraction of the link speed)
+static int copy_rows_staged(jpg_ctx *c, uint8_t *dst, uint32_t pitch, const uint8_t *src, uint32_t stride,
+                            size_t row_bytes, int32_t rows) {
+    for (int k = 0; k < 2; k++) {
+        if (!c->h_bounce[k]) HIP_TRY(c, hipHostMalloc((void **)&c->h_bounce[k], BOUNCE_BYTES, hipHostMallocDefault));
+        if (!c->bounce_done[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->bounce_done[k], hipEventDisableTiming));
+    }
+    const int32_t per = (int32_t)(BOUNCE_BYTES / pitch);
+    if (per < 1) {   // a row longer than a bounce buffer: let the runtime stage it
+        HIP_TRY(c, hipMemcpy2DAsync(dst, pitch, src, stride, row_bytes, (size_t)rows, hipMemcpyHostToDevice, c->stream));
+        return JPG_OK;
+    }
+    int k = 0;
+    bool used[2] = {false, false};
+    for (int32_t r0 = 0; r0 < rows; r0 += per, k ^= 1) {
+        const int32_t n = rows - r0 < per ? rows - r0 : per;
+        if (used[k]) HIP_TRY(c, hipEventSynchronize(c->bounce_done[k]));
+        uint8_t *b = c->h_bounce[k];
+        if (stride == pitch) {
+            memcpy(b, src + (size_t)r0 * stride, (size_t)n * pitch - (pitch - row_bytes));
+        } else {
+            for (int32_t r = 0; r < n; r++) memcpy(b + (size_t)r * pitch, src + (size_t)(r0 + r) * stride, row_bytes);
+        }
+        HIP_TRY(c, hipMemcpyAsync(dst + (size_t)r0 * pitch, b, (size_t)n * pitch, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(c->bounce_done[k], c->stream));
+        used[k] = true;
+    }
+    return JPG_OK;
+}
+
 // Make `pixels` usable by the kernels: device-resident, 4-byte aligned base
 // and stride.  Host memory is always copied; device memory only if misaligned.
 static int stage_input(jpg_ctx *c, const uint8_t *pixels, bool on_host) {
@@ -251,8 +301,12 @@ static int stage_input(jpg_ctx *c, const uint8_t *pixels, bool on_host) {
     }
     const uint32_t pitch = (g.stride & 3) == 0 ? g.stride : (uint32_t)round_up(3 * g.W, 4);
     if (int e = grow(c, c->d_src_own, c->src_cap, (size_t)pitch * g.H + 16)) return e;
-    HIP_TRY(c, hipMemcpy2DAsync(c->d_src_own, pitch, pixels, g.stride, (size_t)3 * g.W, (size_t)g.H,
-                                on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+    if (on_host && !is_pinned_host(pixels)) {
+        if (int e = copy_rows_staged(c, c->d_src_own, pitch, pixels, g.stride, (size_t)3 * g.W, g.H)) return e;
+    } else {
+        HIP_TRY(c, hipMemcpy2DAsync(c->d_src_own, pitch, pixels, g.stride, (size_t)3 * g.W, (size_t)g.H,
+                                    on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+    }
     g.stride = pitch;
     c->d_src = c->d_src_own;
     return JPG_OK;
@@ -516,6 +570,15 @@ extern "C" int jpg_encode_scan(jpg_ctx *c, const uint8_t *pixels, int32_t W, int
     *stuffed = static_cast<uint8_t *>(host);
     *len = c->scan_len;
     return JPG_OK;
+}
+
+extern "C" void *jpg_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
 }
 
 extern "C" void jpg_free(void *p) {

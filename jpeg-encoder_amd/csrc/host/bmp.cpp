@@ -11,7 +11,16 @@ static uint32_t rd_u32(const uint8_t *p) {
     return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
 }
 
-extern "C" int jph_bmp_read(const char *path, jph_bmp *out) {
+static int bmp_read(const char *path, jph_bmp *out, void *(*alloc)(size_t), void (*release)(void *));
+
+extern "C" int jph_bmp_read(const char *path, jph_bmp *out) { return bmp_read(path, out, malloc, free); }
+
+extern "C" int jph_bmp_read_with(const char *path, jph_bmp *out, void *(*alloc)(size_t), void (*release)(void *)) {
+    if (!alloc || !release) return JPH_ERR_ARG;
+    return bmp_read(path, out, alloc, release);
+}
+
+static int bmp_read(const char *path, jph_bmp *out, void *(*alloc)(size_t), void (*release)(void *)) {
     if (!path || !out) return JPH_ERR_ARG;
     memset(out, 0, sizeof *out);
     FILE *f = fopen(path, "rb");
@@ -30,14 +39,15 @@ extern "C" int jph_bmp_read(const char *path, jph_bmp *out) {
     const uint32_t w3 = (uint32_t)out->width * 3u;
     out->row_stride = (w3 + 3u) / 4u * 4u;
     const size_t need = (size_t)out->row_stride * (size_t)out->height;
-    out->pixels = (uint8_t *)malloc(need + 16);
+    out->pixels = (uint8_t *)alloc(need + 16);
     if (!out->pixels) {
         fclose(f);
         return JPH_ERR_NOMEM;
     }
     if (fseek(f, (long)out->data_offset, SEEK_SET) != 0) {
         fclose(f);
-        jph_bmp_free(out);
+        release(out->pixels);
+        out->pixels = nullptr;
         return JPH_ERR_IO;
     }
     const size_t have = fread(out->pixels, 1, need, f);

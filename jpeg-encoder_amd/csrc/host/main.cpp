@@ -164,7 +164,8 @@ int main(int argc, char **argv) {
     std::printf("Loading bmp...\n");
     std::fflush(stdout);
     jph_bmp bmp{};
-    const int be = jph_bmp_read(args.image.c_str(), &bmp);
+    // the pixel array goes straight into page-locked memory, so the device reads it by DMA
+    const int be = jph_bmp_read_with(args.image.c_str(), &bmp, jpg_host_alloc, jpg_free);
     if (be == JPH_ERR_OPEN) panic("Could not open bitmap image file!\n");
     if (be != JPH_OK) panic("could not read the bitmap image file");
     jpg_ctx *ctx = nullptr;
@@ -207,7 +208,7 @@ int main(int argc, char **argv) {
     const int we = jph_jpeg_write(args.output.c_str(), bmp.width, bmp.height, h, v, bytes, scan_len);
     if (scan) jpg_free(scan);
     jpg_destroy(ctx);
-    jph_bmp_free(&bmp);
+    jpg_free(bmp.pixels);
     if (we != JPH_OK) panic("called `Result::unwrap()` on an `Err` value: could not write the output file");
     std::printf("Done!\n");
     return 0;

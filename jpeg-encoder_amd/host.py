@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libjpeg_host.so")
 
-SYMBOLS = ["jph_bmp_read", "jph_bmp_free", "jph_bmp_write", "jph_jfif_header", "jph_jpeg_write",
+SYMBOLS = ["jph_bmp_read", "jph_bmp_read_with", "jph_bmp_free", "jph_bmp_write", "jph_jfif_header", "jph_jpeg_write",
            "jph_jpeg_assemble", "jph_synth_bgr"]
 
 

@@ -275,3 +275,61 @@ def test_full_size_properties(J):
     ref_small = src[:small.shape[0] * k, :small.shape[1] * k].reshape(small.shape[0], k, small.shape[1], k, 3).mean((1, 3))
     psnr = 10 * np.log10(255.0 ** 2 / ((small - ref_small) ** 2).mean())
     assert psnr > 28, psnr
+
+
+# ---- stripes across processes (two ranks sharing the one GPU of the test box, gloo for the scalars)
+
+def _stripe_rank(rank, world, port, tmp):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    import jpeg_encoder_amd as J
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w, h, ratio = 1000, 700, (4, 2, 0)
+        rows = J.host.synth_bgr(w, h, seed=31, noise_only=True)
+        enc = J.Encoder(ratio, "bin-dct", device=0)
+        scan = J.stripes.encode_striped(enc, rows, w, h, rows.shape[1], 2, device="cpu")
+        if rank == 0:
+            whole = J.Encoder(ratio, "bin-dct", device=0).encode_scan(rows, w, h)
+            assert np.array_equal(scan, whole)
+            open(os.path.join(tmp, "ok"), "w").write("%d" % len(scan))
+        else:
+            assert scan is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stripes_two_processes(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_stripe_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert int(open(tmp_path / "ok").read()) > 0
+
+
+def test_page_locked_input_and_large_pageable_input(J, oracle):
+    """Rows in page-locked memory go by DMA, pageable rows through the bounce buffers (several chunks
+    here, with a row stride that is not the packed pitch): same bytes either way."""
+    L = J._native.lib()
+    w, h = 2500, 1400                                            # 10.5 MB of rows: two bounce chunks
+    base = J.host.synth_bgr(w, h, seed=77)
+    ref = oracle.RefImage.from_bgr(base, w, h, base.shape[1], (4, 2, 0), oracle.BIN).encode(threads=3).stuffed_scan()
+    enc = J.Encoder((4, 2, 0), "bin-dct")
+    np.testing.assert_array_equal(enc.encode_scan(base, w, h), ref)
+    wide = np.zeros((h, base.shape[1] + 6), np.uint8)            # misaligned stride -> re-pitched while staging
+    wide[:, :base.shape[1]] = base
+    np.testing.assert_array_equal(enc.encode_scan(wide, w, h, wide.shape[1]), ref)
+    p = L.jpg_host_alloc(base.nbytes)
+    assert p
+    try:
+        C.memmove(p, base.ctypes.data, base.nbytes)
+        pinned = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h, base.shape[1]))
+        np.testing.assert_array_equal(enc.encode_scan(pinned, w, h), ref)
+    finally:
+        enc.close()
+        L.jpg_free(p)
