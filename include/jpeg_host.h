@@ -53,6 +53,17 @@ int jph_jpeg_write(const char *path, int32_t width, int32_t height, int h, int v
 size_t jph_jpeg_assemble(uint8_t *out, size_t cap, int32_t width, int32_t height, int h, int v, const uint8_t *scan,
                          size_t scan_len);
 
+/* ---- stripes: one image cut between MCU rows, one stripe per GPU (no counterpart in the
+ * reference, which codes serially; see jpg_entropy_stripe / jpg_stitch in jpeg_hip.h) ---- */
+
+/* Image rows [y0[k], y1[k]) (top-down) of stripe k of n: whole MCU rows (8*v pixel rows), as even
+ * as possible; stripes may be empty when there are fewer MCU rows than stripes. */
+int jph_plan_stripes(int32_t height, int v, int n, int32_t *y0, int32_t *y1);
+/* nbits[k]: bits of stripe k; tails[k]: its last min(32, nbits[k]) bits, right-aligned
+ * (jpg_stream_tail).  Out: offsets[k] = bit offset of stripe k in the whole scan; heads[k] =
+ * the byte its first byte is OR-ed with (the offsets[k] % 8 bits before it, top-aligned). */
+int jph_stitch_plan(int n, const uint64_t *nbits, const uint32_t *tails, uint64_t *offsets, uint8_t *heads);
+
 /* Deterministic synthetic BMP rows (file order: bottom-up, B,G,R):
  * photo-like sinusoid + ramp + noise, or uniform noise when noise_only != 0. */
 void jph_synth_bgr(uint8_t *rows, int32_t width, int32_t height, uint32_t row_stride, uint64_t seed, int noise_only);

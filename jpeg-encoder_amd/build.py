@@ -32,7 +32,7 @@ HIP_SOURCES = ["front.hip", "staged.hip", "entropy.hip", "api.hip"]
 HIP_HEADERS = ["internal.hpp", "transform.hpp", "tables.h", os.path.join(ROOT, "include", "jpeg_hip.h")]
 LIB_HIP = os.path.join(HERE, "libjpeg_hip.so")
 
-HOST_SOURCES = ["host/bmp.cpp", "host/jfif.cpp"]
+HOST_SOURCES = ["host/bmp.cpp", "host/jfif.cpp", "host/stripes.cpp"]
 HOST_HEADERS = ["tables.h", os.path.join(ROOT, "include", "jpeg_host.h")]
 LIB_HOST = os.path.join(HERE, "libjpeg_host.so")
 CLI = os.path.join(HERE, "jpeg-encoder")

@@ -2,7 +2,8 @@
 // (src/main.rs:8-68, src/utils/arguments.rs:6-66).  Same flags, aliases,
 // defaults, printed lines and exit codes; the five JpegImage calls of main()
 // become the five staged calls of libjpeg_hip.so.  Extra flags (not in the
-// reference): --device N, --fused.
+// reference): --device N, --fused, --stripes N with --devices a,b,.. (one image cut
+// into MCU-row stripes coded on several GPUs), and --image given more than once (a batch).
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,9 @@ const char *USAGE =
     "[default: real-dct] [possible values: real-dct, bin-dct]\n"
     "      --device <N>                             GPU to use [default: 0]\n"
     "      --fused                                  one fused device pass instead of the five stages\n"
+    "      --stripes <N>                            cut the image into N MCU-row stripes coded independently\n"
+    "      --devices <A,B,..>                       GPUs the stripes (or the images of a batch) are spread over\n"
+    "                                               (--image may be given several times: a batch)\n"
     "  -h, --help                                   Print help\n"
     "  -V, --version                                Print version\n";
 
@@ -44,9 +48,12 @@ const char *USAGE =
 }
 
 struct Args {
-    std::string image, output, ratio_text = "4:2:0", dct = "real-dct";
+    std::string output, ratio_text = "4:2:0", dct = "real-dct";
+    std::vector<std::string> images;   // all --image values
     int ratio[3] = {4, 2, 0};
     int device = 0;
+    std::vector<int> devices;
+    int stripes = 0;
     bool fused = false;
 };
 
@@ -114,7 +121,7 @@ Args parse(int argc, char **argv) {
             std::printf("jpeg-encoder 0.1.0\n");
             std::exit(0);
         } else if (key == "-i" || key == "--image") {
-            a.image = value(i, "--image <IMAGE>", inl);
+            a.images.push_back(value(i, "--image <IMAGE>", inl));
             have_image = true;
         } else if (key == "-o" || key == "--output") {
             a.output = value(i, "--output <OUTPUT>", inl);
@@ -129,19 +136,39 @@ Args parse(int argc, char **argv) {
             a.device = std::atoi(value(i, "--device <N>", inl).c_str());
         } else if (key == "--fused") {
             a.fused = true;
+        } else if (key == "--stripes") {
+            a.stripes = std::atoi(value(i, "--stripes <N>", inl).c_str());
+            if (a.stripes < 1 || a.stripes > 4096) usage_error("invalid value for '--stripes <N>'");
+        } else if (key == "--devices") {
+            const std::string list = value(i, "--devices <A,B,..>", inl);
+            size_t p0 = 0;
+            while (p0 <= list.size()) {
+                const size_t p1 = list.find(',', p0);
+                const std::string tok = list.substr(p0, p1 == std::string::npos ? p1 : p1 - p0);
+                if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos)
+                    usage_error("invalid value '" + list + "' for '--devices <A,B,..>'");
+                a.devices.push_back(std::atoi(tok.c_str()));
+                if (p1 == std::string::npos) break;
+                p0 = p1 + 1;
+            }
         } else {
             usage_error("unexpected argument '" + arg + "' found");
         }
     }
     if (!have_image) usage_error("the following required arguments were not provided:\n  --image <IMAGE>");
     parse_ratio(a.ratio_text, a.ratio);
+    if (a.devices.empty()) a.devices.push_back(a.device);
+    if (a.images.size() > 1 && !a.output.empty()) usage_error("'--output <OUTPUT>' cannot be used with several images");
     // Args::get_args (src/utils/arguments.rs:46-58)
-    const std::string ext = ".bmp";
-    if (a.image.size() < ext.size() || a.image.compare(a.image.size() - ext.size(), ext.size(), ext) != 0)
-        panic("Input image must be a .bmp file\n");
-    if (a.output.empty()) a.output = a.image.substr(0, a.image.size() - ext.size()) + ".jpeg";
+    for (const std::string &im : a.images) {
+        const std::string ext = ".bmp";
+        if (im.size() < ext.size() || im.compare(im.size() - ext.size(), ext.size(), ext) != 0)
+            panic("Input image must be a .bmp file\n");
+    }
     return a;
 }
+
+std::string default_output(const std::string &image) { return image.substr(0, image.size() - 4) + ".jpeg"; }
 
 [[noreturn]] void fail(jpg_ctx *ctx, int status) {
     std::string msg = jpg_strerror(status);
@@ -150,29 +177,83 @@ Args parse(int argc, char **argv) {
     panic(msg.c_str());
 }
 
-}  // namespace
+// One image cut into stripes: every stripe is transformed and coded by its own context (spread
+// over the devices), the few scalars that link neighbouring stripes pass through the host, and the
+// stuffed pieces are concatenated.  Returns the whole scan.
+std::vector<uint8_t> encode_striped(const Args &args, const jph_bmp &bmp, int v) {
+    const int n = args.stripes;
+    std::vector<int32_t> y0(n), y1(n);
+    if (jph_plan_stripes(bmp.height, v, n, y0.data(), y1.data()) != JPH_OK) panic("bad stripe plan");
+    std::vector<jpg_ctx *> ctx(n, nullptr);
+    auto fail_all = [&](int k, int st) {
+        jpg_ctx *bad = ctx[k];
+        for (int j = 0; j < n; j++)
+            if (ctx[j] && ctx[j] != bad) jpg_destroy(ctx[j]);
+        fail(bad, st);
+    };
+    const int algo = args.dct == "bin-dct" ? JPG_DCT_BIN : JPG_DCT_REAL;
+    for (int k = 0; k < n; k++) {   // the transforms of all stripes run concurrently (one stream per context)
+        if (y1[k] <= y0[k]) continue;
+        int st = jpg_create(&ctx[k], args.devices[k % args.devices.size()], algo, args.ratio[0], args.ratio[1], args.ratio[2]);
+        if (st != JPG_OK) fail_all(k, st);
+        const uint8_t *rows = bmp.pixels + (size_t)(bmp.height - y1[k]) * bmp.row_stride;   // bottom-up file rows
+        if ((st = jpg_front_host(ctx[k], rows, bmp.width, y1[k] - y0[k], bmp.row_stride, 1)) != JPG_OK) fail_all(k, st);
+    }
+    std::vector<uint64_t> nbits(n, 0), offsets(n, 0);
+    std::vector<uint32_t> tails(n, 0);
+    std::vector<uint8_t> heads(n, 0);
+    int16_t pred[3] = {0, 0, 0};   // src/jpeg/entropy_coding.rs:38-40
+    int last = -1;
+    for (int k = 0; k < n; k++) {
+        if (!ctx[k]) continue;
+        int st;
+        if ((st = jpg_entropy_stripe(ctx[k], pred, &nbits[k])) != JPG_OK) fail_all(k, st);
+        if ((st = jpg_stream_tail(ctx[k], &tails[k])) != JPG_OK) fail_all(k, st);
+        if ((st = jpg_last_dc(ctx[k], pred)) != JPG_OK) fail_all(k, st);
+        last = k;
+    }
+    jph_stitch_plan(n, nbits.data(), tails.data(), offsets.data(), heads.data());
+    std::vector<uint8_t> scan;
+    for (int k = 0; k < n; k++) {
+        if (!ctx[k]) continue;
+        size_t len = 0;
+        uint8_t tail = 0;
+        int st = jpg_stitch(ctx[k], offsets[k], heads[k], k == last, &len, &tail);
+        if (st != JPG_OK) fail_all(k, st);
+        const size_t at = scan.size();
+        scan.resize(at + len);
+        if (len && (st = jpg_get_scan(ctx[k], scan.data() + at, len)) != JPG_OK) fail_all(k, st);
+    }
+    for (int k = 0; k < n; k++)
+        if (ctx[k]) jpg_destroy(ctx[k]);
+    return scan;
+}
 
-int main(int argc, char **argv) {
-    const Args args = parse(argc, argv);
-    // Args::print_args (src/utils/arguments.rs:60-66)
-    std::printf("image: \"%s\"\n", args.image.c_str());
-    std::printf("output: \"%s\"\n", args.output.c_str());
-    std::printf("subsampling ratio: \"(%d, %d, %d)\"\n", args.ratio[0], args.ratio[1], args.ratio[2]);
-    std::printf("dct algorithm: \"%s\"\n", args.dct == "bin-dct" ? "BinDct" : "RealDct");
-    std::printf("\n");
-
+void encode_one(const Args &args, const std::string &image, const std::string &output, int device) {
     std::printf("Loading bmp...\n");
     std::fflush(stdout);
     jph_bmp bmp{};
     // the pixel array goes straight into page-locked memory, so the device reads it by DMA
-    const int be = jph_bmp_read_with(args.image.c_str(), &bmp, jpg_host_alloc, jpg_free);
+    const int be = jph_bmp_read_with(image.c_str(), &bmp, jpg_host_alloc, jpg_free);
     if (be == JPH_ERR_OPEN) panic("Could not open bitmap image file!\n");
     if (be != JPH_OK) panic("could not read the bitmap image file");
+    const int h = 1 + (args.ratio[1] == 2), v = 1 + (args.ratio[1] == 2 && args.ratio[2] == 0);
+    if (args.stripes > 0) {
+        const std::vector<uint8_t> scan = encode_striped(args, bmp, v);
+        std::printf("Loaded!\nChrominance downsampling...\nDone!\n");
+        std::printf("Performing Discrete Cosine Transform + Quantization...\nDone!\nEntropy encoding...\nDone!\n");
+        std::printf("Creating file\n");
+        std::fflush(stdout);
+        const int we = jph_jpeg_write(output.c_str(), bmp.width, bmp.height, h, v, scan.data(), scan.size());
+        jpg_free(bmp.pixels);
+        if (we != JPH_OK) panic("called `Result::unwrap()` on an `Err` value: could not write the output file");
+        std::printf("Done!\n");
+        return;
+    }
     jpg_ctx *ctx = nullptr;
-    int st = jpg_create(&ctx, args.device, args.dct == "bin-dct" ? JPG_DCT_BIN : JPG_DCT_REAL, args.ratio[0], args.ratio[1],
+    int st = jpg_create(&ctx, device, args.dct == "bin-dct" ? JPG_DCT_BIN : JPG_DCT_REAL, args.ratio[0], args.ratio[1],
                         args.ratio[2]);
     if (st != JPG_OK) fail(ctx, st);
-    const int h = 1 + (args.ratio[1] == 2), v = 1 + (args.ratio[1] == 2 && args.ratio[2] == 0);
 
     uint8_t *scan = nullptr;
     size_t scan_len = 0;
@@ -205,11 +286,28 @@ int main(int argc, char **argv) {
         if ((st = jpg_get_scan(ctx, staged_scan.data(), staged_scan.size())) != JPG_OK) fail(ctx, st);
     }
     const uint8_t *bytes = args.fused ? scan : staged_scan.data();
-    const int we = jph_jpeg_write(args.output.c_str(), bmp.width, bmp.height, h, v, bytes, scan_len);
+    const int we = jph_jpeg_write(output.c_str(), bmp.width, bmp.height, h, v, bytes, scan_len);
     if (scan) jpg_free(scan);
     jpg_destroy(ctx);
     jpg_free(bmp.pixels);
     if (we != JPH_OK) panic("called `Result::unwrap()` on an `Err` value: could not write the output file");
     std::printf("Done!\n");
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    const Args args = parse(argc, argv);
+    for (size_t k = 0; k < args.images.size(); k++) {
+        const std::string &image = args.images[k];
+        const std::string output = args.output.empty() ? default_output(image) : args.output;
+        // Args::print_args (src/utils/arguments.rs:60-66)
+        std::printf("image: \"%s\"\n", image.c_str());
+        std::printf("output: \"%s\"\n", output.c_str());
+        std::printf("subsampling ratio: \"(%d, %d, %d)\"\n", args.ratio[0], args.ratio[1], args.ratio[2]);
+        std::printf("dct algorithm: \"%s\"\n", args.dct == "bin-dct" ? "BinDct" : "RealDct");
+        std::printf("\n");
+        encode_one(args, image, output, args.devices[k % args.devices.size()]);
+    }
     return 0;
 }

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libjpeg_host.so")
 
 SYMBOLS = ["jph_bmp_read", "jph_bmp_read_with", "jph_bmp_free", "jph_bmp_write", "jph_jfif_header", "jph_jpeg_write",
-           "jph_jpeg_assemble", "jph_synth_bgr"]
+           "jph_jpeg_assemble", "jph_synth_bgr", "jph_plan_stripes", "jph_stitch_plan"]
 
 
 class _Bmp(C.Structure):
@@ -38,6 +38,9 @@ def lib():
     L.jph_jpeg_assemble.restype = C.c_size_t
     L.jph_synth_bgr.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_uint64, C.c_int]
     L.jph_synth_bgr.restype = None
+    L.jph_plan_stripes.argtypes = [C.c_int32, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.jph_stitch_plan.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                  C.POINTER(C.c_uint8)]
     _lib = L
     return L
 
@@ -99,3 +102,22 @@ def synth_bgr(width, height, seed=0, noise_only=False, stride=None):
     rows = np.zeros((height, stride), np.uint8)
     lib().jph_synth_bgr(rows.ctypes.data, width, height, stride, seed, int(noise_only))
     return rows
+
+
+def plan_stripes(height, v, n):
+    """jph_plan_stripes: [(y0, y1)] per stripe (the C twin of stripes.plan_stripes)."""
+    y0, y1 = (C.c_int32 * n)(), (C.c_int32 * n)()
+    e = lib().jph_plan_stripes(height, v, n, y0, y1)
+    if e:
+        raise ValueError("jph_plan_stripes: status %d" % e)
+    return list(zip(y0, y1))
+
+
+def stitch_plan(nbits, tails):
+    """jph_stitch_plan: (offsets, heads) (the C twin of stripes.stitch_plan)."""
+    n = len(nbits)
+    off, heads = (C.c_uint64 * n)(), (C.c_uint8 * n)()
+    e = lib().jph_stitch_plan(n, (C.c_uint64 * n)(*nbits), (C.c_uint32 * n)(*tails), off, heads)
+    if e:
+        raise ValueError("jph_stitch_plan: status %d" % e)
+    return list(off), list(heads)

@@ -72,3 +72,32 @@ def test_cli_writes_the_reference_file(J, oracle, tmp_path, flags, ratio, algo):
     out2 = str(tmp_path / "other.jpg")
     r = run("--image", bmp, "--output", out2, "-d", "bin-dct")
     assert r.returncode == 0 and os.path.getsize(out2) > 623
+
+
+@pytest.mark.gpu
+def test_cli_stripes_and_batch(J, oracle, tmp_path):
+    w, h = 300, 260
+    paths = []
+    for k in range(3):
+        rows = J.host.synth_bgr(w, h, seed=40 + k, noise_only=bool(k & 1))
+        p = str(tmp_path / ("im%d.bmp" % k))
+        J.host.write_bmp(p, rows, w, h)
+        paths.append(p)
+    # one image in 5 stripes (all on device 0 here) == the whole image
+    r = run("-i", paths[0], "-d", "bin-dct", "--stripes", "5", "--devices", "0,0")
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines()[5:] == BANNERS
+    want = oracle.RefImage.from_bmp(paths[0], (4, 2, 0), oracle.BIN).encode().file_bytes()
+    assert open(tmp_path / "im0.jpeg", "rb").read() == want
+    # a batch: --image several times, default output names
+    args = []
+    for p in paths:
+        args += ["-i", p]
+    r = run(*args, "-d", "bin-dct", "-s", "4:2:2")
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("Creating file") == 3
+    for k, p in enumerate(paths):
+        want = oracle.RefImage.from_bmp(p, (4, 2, 2), oracle.BIN).encode().file_bytes()
+        assert open(tmp_path / ("im%d.jpeg" % k), "rb").read() == want
+    r = run(*args, "-o", str(tmp_path / "x.jpeg"))
+    assert r.returncode == 2

@@ -25,6 +25,7 @@ def test_plan_covers_the_image(J):
                     assert (a % (8 * v) == 0 or a == H) and (b % (8 * v) == 0 or b == H)
                 sizes = [(b - a + 8 * v - 1) // (8 * v) for a, b in plan]
                 assert max(sizes) - min(sizes) <= 1
+                assert J.host.plan_stripes(H, v, n) == plan               # the C twin used by the CLI
     assert S.plan_stripes(4320, 2, 8)[0] == (0, 544)            # 270 MCU rows: 34,34,34,34,34,34,33,33
     rows = np.arange(10)[:, None] * np.ones((1, 4), int)
     assert S.stripe_rows(rows, 10, 2, 5, bottom_up=True)[:, 0].tolist() == [5, 6, 7]
@@ -42,6 +43,7 @@ def test_stitch_plan_heads(J):
         offsets, heads = S.stitch_plan(lens, tails)
         whole = np.concatenate(streams + [np.zeros(0, int)]).astype(int)
         assert offsets == [int(sum(lens[:k])) for k in range(n)]
+        assert J.host.stitch_plan(lens, tails) == (offsets, heads)    # the C twin used by the CLI
         for k in range(n):
             r = offsets[k] % 8
             want = whole[offsets[k] - r:offsets[k]]
