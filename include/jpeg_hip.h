@@ -108,6 +108,13 @@ int jpg_front_host(jpg_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t h
  * stream without any host synchronisation.  jpg_finish() waits and reports. */
 int jpg_encode_device_async(jpg_ctx *ctx, const uint8_t *dev_pixels, int32_t width, int32_t height,
                             uint32_t row_stride, int bottom_up);
+/* Measurement aid: with every = n > 0, every n-th fused front launch (jpg_front_device/_host,
+ * jpg_encode_device_async, jpg_encode_scan) hands two events to the dispatch, which receive
+ * the kernel's own start and end time stamps (0 switches it off); jpg_front_time waits for
+ * the stream and returns the summed duration of those launches in milliseconds and their
+ * number.  No counterpart in the reference. */
+int jpg_set_timing(jpg_ctx *ctx, int every);
+int jpg_front_time(jpg_ctx *ctx, double *total_ms, uint64_t *launches);
 /* Page-locked host memory (release with jpg_free).  Rows handed to jpg_load_bgr,
  * jpg_front_host or jpg_encode_scan from such memory are copied by DMA at full
  * link speed; ordinary (pageable) memory is staged through the library's own

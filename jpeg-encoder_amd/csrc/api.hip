@@ -38,6 +38,14 @@ struct jpg_ctx {
     // two page-locked bounce buffers for rows that arrive in pageable host memory
     uint8_t *h_bounce[2] = {nullptr, nullptr};
     hipEvent_t bounce_done[2] = {nullptr, nullptr};
+    // optional timing of the front kernel: a ring of event pairs, harvested by jpg_front_time
+    int timing = 0;             // 0 = off, n = bracket every n-th front launch
+    uint64_t t_seen = 0;
+    static constexpr int TIMING_RING = 256;
+    hipEvent_t t_ev[2 * TIMING_RING] = {};
+    int t_pending = 0;
+    double t_total_ms = 0.0;
+    uint64_t t_count = 0;
     DevStatus *h_status = nullptr;  // pinned copy of eb.status
     int16_t *h_dc = nullptr;        // pinned
     uint64_t nbits = 0;
@@ -157,6 +165,8 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
                    c->eb.bits, c->eb.sagg, c->eb.sgrp, c->eb.shyp, c->eb.scan};
     for (void *p : dev)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->t_ev)
+        if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; k++) {
         if (c->h_bounce[k]) (void)hipHostFree(c->h_bounce[k]);
         if (c->bounce_done[k]) (void)hipEventDestroy(c->bounce_done[k]);
@@ -373,6 +383,59 @@ extern "C" int jpg_dct_quant(jpg_ctx *c) {
     return JPG_OK;
 }
 
+// add the elapsed times of the recorded event pairs to the totals (the stream must be idle)
+static int harvest_timing(jpg_ctx *c) {
+    for (int k = 0; k < c->t_pending; k++) {
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->t_ev[2 * k], c->t_ev[2 * k + 1]));
+        c->t_total_ms += ms;
+        c->t_count++;
+    }
+    c->t_pending = 0;
+    return JPG_OK;
+}
+
+// the fused front kernel, with its start and end time stamps taken when timing is on
+static int queue_front(jpg_ctx *c) {
+    if (!c->timing || (c->t_seen++ % (uint64_t)c->timing) != 0) {
+        HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream));
+        return JPG_OK;
+    }
+    if (c->t_pending == jpg_ctx::TIMING_RING) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (int e = harvest_timing(c)) return e;
+    }
+    hipEvent_t &e0 = c->t_ev[2 * c->t_pending], &e1 = c->t_ev[2 * c->t_pending + 1];
+    if (!e0) HIP_TRY(c, hipEventCreate(&e0));
+    if (!e1) HIP_TRY(c, hipEventCreate(&e1));
+    // the events take the dispatch's own time stamps: no extra packets in the stream
+    HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream, e0, e1));
+    c->t_pending++;
+    return JPG_OK;
+}
+
+extern "C" int jpg_set_timing(jpg_ctx *c, int every) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (int e = use_device(c)) return e;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->t_pending = 0;
+    c->t_total_ms = 0.0;
+    c->t_count = 0;
+    c->t_seen = 0;
+    c->timing = every > 0 ? every : 0;
+    return JPG_OK;
+}
+
+extern "C" int jpg_front_time(jpg_ctx *c, double *total_ms, uint64_t *launches) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (int e = use_device(c)) return e;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int e = harvest_timing(c)) return e;
+    if (total_ms) *total_ms = c->t_total_ms;
+    if (launches) *launches = c->t_count;
+    return JPG_OK;
+}
+
 static int queue_entropy(jpg_ctx *c, const int16_t pred[3]) {
     if (int e = ensure_entropy(c)) return e;
     // errors are tagged with a launch number; clear the word before the number repeats
@@ -493,7 +556,7 @@ extern "C" int jpg_front_device(jpg_ctx *c, const uint8_t *dev_pixels, int32_t W
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
     if (int e = stage_input(c, dev_pixels, false)) return e;
     if (int e = ensure_coef(c)) return e;
-    HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream));
+    if (int e = queue_front(c)) return e;
     c->stage = ST_COEF;
     return JPG_OK;
 }
@@ -505,7 +568,7 @@ extern "C" int jpg_front_host(jpg_ctx *c, const uint8_t *pixels, int32_t W, int3
     if (int e = stage_input(c, pixels, true)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // caller may reuse `pixels`
     if (int e = ensure_coef(c)) return e;
-    HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream));
+    if (int e = queue_front(c)) return e;
     c->stage = ST_COEF;
     return JPG_OK;
 }
@@ -555,7 +618,7 @@ extern "C" int jpg_encode_scan(jpg_ctx *c, const uint8_t *pixels, int32_t W, int
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
     if (int e = stage_input(c, pixels, true)) return e;
     if (int e = ensure_coef(c)) return e;
-    HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream));
+    if (int e = queue_front(c)) return e;
     c->stage = ST_COEF;
     if (int e = queue_entropy(c, nullptr)) return e;
     if (int e = queue_stuff(c, 0, 0, 1)) return e;

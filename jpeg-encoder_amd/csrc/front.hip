@@ -17,6 +17,8 @@
 //            memory as coalesced 16-byte stores.
 // HBM traffic is the algorithmic minimum: every input byte is read once, every
 // coefficient written once.
+#include <hip/hip_ext.h>
+
 #include "internal.hpp"
 #include "transform.hpp"
 
@@ -207,28 +209,31 @@ __global__ __launch_bounds__(THREADS) void k_front(const uint8_t *__restrict__ s
         dst[u] = *reinterpret_cast<const uint4 *>(&lds[(u >> 3) * OUT_STRIDE + (u & 7) * 16]);
 }
 
+// e0/e1 (both or neither): events that receive the kernel's own start and end time stamps
 template <int HS, int VS>
-static hipError_t launch_front_hv(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s) {
+static hipError_t launch_front_hv(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s,
+                                  hipEvent_t e0, hipEvent_t e1) {
     using C = TileCfg<HS, VS>;
     const int tiles_x = (g.mcux + C::MCUS - 1) / C::MCUS;
     const dim3 grid((unsigned)(tiles_x * g.mcuy)), block(THREADS);
     switch (algo) {
-        case ALGO_REAL: hipLaunchKernelGGL((k_front<HS, VS, ALGO_REAL>), grid, block, 0, s, src, g, coef); break;
-        case ALGO_BIN: hipLaunchKernelGGL((k_front<HS, VS, ALGO_BIN>), grid, block, 0, s, src, g, coef); break;
+        case ALGO_REAL: hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, src, g, coef); break;
+        case ALGO_BIN: hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, src, g, coef); break;
         case ALGO_REAL_STRICT:
-            hipLaunchKernelGGL((k_front<HS, VS, ALGO_REAL_STRICT>), grid, block, 0, s, src, g, coef);
+            hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_REAL_STRICT>), grid, block, 0, s, e0, e1, 0, src, g, coef);
             break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_front(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s) {
+hipError_t launch_front(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s, hipEvent_t e0,
+                        hipEvent_t e1) {
     // the fast path reads rows as dwords
     if ((reinterpret_cast<uintptr_t>(src) & 3) || (g.stride & 3)) return hipErrorInvalidValue;
-    if (g.h == 2 && g.v == 2) return launch_front_hv<2, 2>(g, algo, src, coef, s);
-    if (g.h == 2 && g.v == 1) return launch_front_hv<2, 1>(g, algo, src, coef, s);
-    if (g.h == 1 && g.v == 1) return launch_front_hv<1, 1>(g, algo, src, coef, s);
+    if (g.h == 2 && g.v == 2) return launch_front_hv<2, 2>(g, algo, src, coef, s, e0, e1);
+    if (g.h == 2 && g.v == 1) return launch_front_hv<2, 1>(g, algo, src, coef, s, e0, e1);
+    if (g.h == 1 && g.v == 1) return launch_front_hv<1, 1>(g, algo, src, coef, s, e0, e1);
     return hipErrorInvalidValue;
 }
 

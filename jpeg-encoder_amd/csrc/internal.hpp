@@ -72,7 +72,9 @@ struct EntropyBufs {
     unsigned long long *trace;  // debug builds only (JPG_TRACE): phase stamps of the stream kernel
 };
 
-hipError_t launch_front(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s);
+// e0/e1: optional events that receive the kernel's own start and end time stamps
+hipError_t launch_front(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s,
+                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 hipError_t launch_color(const Geom &g, const uint8_t *src, uint8_t *y, uint8_t *cb, uint8_t *cr, hipStream_t s);
 hipError_t launch_downsample(const Geom &g, const uint8_t *cb, const uint8_t *cr, uint8_t *cb_out, uint8_t *cr_out,
                              hipStream_t s);

@@ -181,6 +181,16 @@ class Encoder:
     def bits_device_ptr(self):
         return self._L.jpg_bits_device(self._ctx)
 
+    def set_timing(self, every=1):
+        """Bracket every n-th front launch with events (0 = off)."""
+        self._ck(self._L.jpg_set_timing(self._ctx, int(every)))
+
+    def front_time(self):
+        """(summed milliseconds, number) of the bracketed front launches since set_timing."""
+        ms, n = C.c_double(), C.c_uint64()
+        self._ck(self._L.jpg_front_time(self._ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def front_bytes(self):
         return self._L.jpg_front_bytes(self._ctx)
 
