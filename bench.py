@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json config 3): 7680x4320 24-bit BMP rows, 4:2:0, real-dct.
+Workload: 7680x4320 24-bit BMP rows, 4:2:0, real-dct (the configuration the headline metric is quoted on).
 One step = every rank encodes its own batch of `--batch` distinct synthetic
 8K images (device-resident BMP rows -> stuffed JPEG scan bytes in HBM): colour
 conversion + subsampling + DCT + quantisation (one fused kernel), entropy

@@ -162,7 +162,7 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_src_own, c->d_plane[0], c->d_plane[1], c->d_plane[2], c->d_down[0], c->d_down[1], c->d_coef,
                    c->d_tmp16, c->d_dc, c->eb.clen, c->eb.sparse, c->eb.status,
-                   c->eb.bits, c->eb.sagg, c->eb.sgrp, c->eb.shyp, c->eb.scan};
+                   c->eb.bits, c->eb.sagg, c->eb.sgrp, c->eb.shyp, c->eb.scan, c->eb.trace};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->t_ev)
@@ -231,6 +231,7 @@ static int ensure_entropy(jpg_ctx *c) {
     if ((nchunks + 63) / 64 > (size_t)MAX_GROUPS) return JPG_ERR_CAPACITY;
     c->eb.nchunks = (long long)nchunks;
     if (nblk <= c->ent_cap) return JPG_OK;
+    c->ent_cap = 0;   // nothing is usable until every buffer below has been replaced
     const size_t bits_bytes = worst_bits_bytes(nblk);
     const size_t scan_bytes = 2 * bits_bytes + 16;
     const size_t nseg = bits_bytes / STUFF_SEG + 2;

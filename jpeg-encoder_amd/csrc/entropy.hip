@@ -806,7 +806,10 @@ static hipError_t launch_stream(const EntropyBufs &b, StreamArgs a, hipStream_t 
     if (resident == 0) {
         int cus = 0, per_cu = 0;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<STUFF>, ST_THREADS, lds);
+        // (with the largest dynamic LDS the kernel is ever launched with, so the figure holds for every image)
+        if (e == hipSuccess)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<STUFF>, ST_THREADS,
+                                                             (MAX_GROUPS + 1) * sizeof(uint64_t));
         if (e != hipSuccess) return e;
         resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
         if (dev >= 0 && dev < 64) resident_cache[STUFF][dev] = resident;

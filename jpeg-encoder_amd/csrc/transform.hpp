@@ -87,20 +87,6 @@ __device__ __forceinline__ void store_zigzag(const int (&res)[64], uint32_t *slo
     }
 }
 
-// place quantised value n at zigzag position K of the packed block w[32];
-// `first` tells whether the other half of that dword is still unwritten
-template <int K>
-__device__ __forceinline__ void put16(uint32_t (&w)[32], int n, bool first) {
-    if (K & 1) w[K >> 1] = first ? ((uint32_t)n << 16) : (w[K >> 1] | ((uint32_t)n << 16));
-    else w[K >> 1] = first ? ((uint32_t)n & 0xffffu) : (w[K >> 1] | ((uint32_t)n & 0xffffu));
-}
-
-// same with the position as a (compile-time foldable) argument
-__device__ __forceinline__ void put16_rt(uint32_t (&w)[32], int k, int n, bool first) {
-    const uint32_t half = (k & 1) ? ((uint32_t)n << 16) : ((uint32_t)n & 0xffffu);
-    w[k >> 1] = first ? half : (w[k >> 1] | half);
-}
-
 __device__ __forceinline__ void store_packed(const uint32_t (&w)[32], uint32_t *slot) {
     uint4 *s4 = reinterpret_cast<uint4 *>(slot);
 #pragma unroll
@@ -366,17 +352,5 @@ __device__ __forceinline__ void cvt_pack8(uint32_t &d, float x) {
     else asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(x));
 }
 
-
-// the same on two pixels at once (packed f32; products and sums stay unfused)
-__device__ __forceinline__ void rgb_to_ycbcr2(f2 r, f2 g, f2 b, f2 &y, f2 &cb, f2 &cr) {
-    y = 0.299f * r + 0.587f * g;
-    y = y + 0.114f * b;
-    cb = 128.0f - 0.168736f * r;
-    cb = cb - 0.331264f * g;
-    cb = __builtin_elementwise_fma((f2){0.5f, 0.5f}, b, cb);                  // 0.5*b is exact
-    cr = __builtin_elementwise_fma((f2){0.5f, 0.5f}, r, (f2){128.0f, 128.0f});  // exact
-    cr = cr - 0.418688f * g;
-    cr = cr - 0.081312f * b;
-}
 
 }  // namespace jpg

@@ -333,3 +333,23 @@ def test_page_locked_input_and_large_pageable_input(J, oracle):
     finally:
         enc.close()
         L.jpg_free(p)
+
+
+def test_kernel_time_stamps(J):
+    """jpg_set_timing / jpg_front_time: sampled start/end stamps of the fused kernel."""
+    import torch
+    w, h = 1920, 1080
+    rows = J.host.synth_bgr(w, h, seed=2)
+    t = torch.from_numpy(rows).cuda()
+    torch.cuda.synchronize()
+    enc = J.Encoder((4, 2, 0), "real-dct")
+    enc.set_timing(2)
+    for _ in range(10):
+        enc.encode_device_async(t.data_ptr(), w, h, rows.shape[1], True)
+        enc.finish()
+    ms, n = enc.front_time()
+    assert n == 5 and 0.0005 < ms / n < 5.0
+    enc.set_timing(0)
+    enc.encode_device_async(t.data_ptr(), w, h, rows.shape[1], True)
+    enc.finish()
+    assert enc.front_time() == (0.0, 0)
