@@ -39,6 +39,7 @@ def parse():
                     help="encoder contexts (each with its own stream and buffers) the batch alternates over; "
                          "2 overlaps the tail of one encode with the front kernel of the next (higher MP/s, but "
                          "the kernels then share the device and their individual durations grow)")
+    ap.add_argument("--depth", type=int, default=2, choices=[1, 2, 3], help="encodes in flight per context")
     ap.add_argument("--time-every", type=int, default=16,
                     help="take the start/end time stamps of every n-th front-kernel launch of the timed region "
                          "(roofline figure); a stamped launch costs some host time, hence the sampling")
@@ -118,17 +119,21 @@ def main():
     enc = encs[0]
 
     def step():
+        # every image's result is taken (sizes read back) before its buffers are reused; a context keeps
+        # up to two encodes in flight, so the stuffing of one image overlaps the front kernel of the next
         res = None
-        busy = [False] * len(encs)
+        inflight = [0] * len(encs)
         for i, t in enumerate(imgs):
             k = i % len(encs)
-            if busy[k]:
-                res = encs[k].finish()       # one encode in flight per context
+            if inflight[k] == args.depth:
+                res = encs[k].finish_next()
+                inflight[k] -= 1
             encs[k].encode_device_async(t.data_ptr(), W, H, stride, True)
-            busy[k] = True
+            inflight[k] += 1
         for k, e in enumerate(encs):
-            if busy[k]:
-                res = e.finish()
+            while inflight[k]:
+                res = e.finish_next()
+                inflight[k] -= 1
         return res
 
     for _ in range(args.warmup):
@@ -208,7 +213,7 @@ def main():
             "dtype": "f32" if args.dct_algorithm.startswith("real") else "int32",
             "data": "synthetic" + (" (uniform noise)" if args.noise else ""),
             "config": {"workload": "%dx%d BMP, %s, %s" % (W, H, args.ratio, args.dct_algorithm),
-                       "images_per_rank_per_step": args.batch, "contexts_per_rank": len(encs), "global_batch": args.batch * world,
+                       "images_per_rank_per_step": args.batch, "contexts_per_rank": len(encs), "encodes_in_flight_per_context": args.depth, "global_batch": args.batch * world,
                        "parallelism": "image-sharded x%d" % world, "scan_bytes_last_image": int(scan_len),
                        "bits_per_pixel": round(nbits / (W * H), 4)},
             "roofline": roof,

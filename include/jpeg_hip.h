@@ -124,6 +124,14 @@ void *jpg_host_alloc(size_t bytes);
  * reference's range errors (JPG_ERR_DC_RANGE/JPG_ERR_AC_RANGE) if a kernel
  * met a coefficient the Huffman tables cannot code. */
 int jpg_finish(jpg_ctx *ctx, uint64_t *nbits, size_t *stuffed_len);
+/* Up to three fused encodes may be in flight on a context: the byte stuffing of one image runs
+ * on a second stream while the front and entropy kernels of the next image run on the first
+ * (three sets of output buffers).  jpg_finish_next waits for the OLDEST queued encode only and
+ * reports it; its scan stays readable (jpg_scan_device, jpg_get_scan) until three more encodes
+ * have been queued.  Queuing a fourth encode before taking the first overwrites the first's
+ * result.  jpg_finish waits for everything and reports the newest.  No counterpart in the
+ * reference. */
+int jpg_finish_next(jpg_ctx *ctx, uint64_t *nbits, size_t *stuffed_len);
 /* everything above from host pixels to a host copy of the stuffed scan bytes
  * (library-allocated pinned memory; release with jpg_free) */
 int jpg_encode_scan(jpg_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t height,

@@ -22,8 +22,6 @@ struct jpg_ctx {
     int stage = ST_NONE;
     bool have_planes = false;   // staged u8 planes are valid
     bool down_done = false;
-    bool pending = false;       // an async encode awaits jpg_finish
-    bool dense_valid = false;   // eb.bits holds the dense stream of the last entropy launch
     Geom g{};
 
     uint8_t *d_src_own = nullptr; size_t src_cap = 0;
@@ -33,8 +31,25 @@ struct jpg_ctx {
     int16_t *d_coef = nullptr; size_t coef_cap = 0;                            // in blocks
     int16_t *d_tmp16 = nullptr; size_t tmp16_cap = 0;
     int16_t *d_dc = nullptr;     // last DCs out (3 values)
-    EntropyBufs eb{};
-    size_t ent_cap = 0;          // in blocks
+    static constexpr int NSLOT = 3;
+    // Sets of back-end buffers: while the stuffing kernel of one image runs on stream_b, the
+    // front and entropy kernels of the next image run on `stream` into the other set.
+    struct Slot {
+        EntropyBufs eb{};
+        size_t ent_cap = 0;             // in blocks
+        DevStatus *h_status = nullptr;  // pinned copy of eb.status
+        hipEvent_t e_done = nullptr;    // entropy kernel finished (recorded on stream)
+        hipEvent_t s_done = nullptr;    // stuffing kernel finished (recorded on the stream it ran on)
+        bool busy = false;              // s_done has been recorded at least once
+        bool dense_valid = false;       // eb.bits holds the dense stream of the last entropy launch
+        uint64_t nbits = 0;
+        size_t scan_len = 0;
+    } slot[NSLOT];
+    int cur = 0;                 // slot of the most recent entropy launch
+    int view = 0;                // slot whose results the getters show
+    int fifo[NSLOT] = {};        // slots of queued fused encodes that jpg_finish_next has not handed out yet
+    int npend = 0;
+    hipStream_t stream_b = nullptr;
     // two page-locked bounce buffers for rows that arrive in pageable host memory
     uint8_t *h_bounce[2] = {nullptr, nullptr};
     hipEvent_t bounce_done[2] = {nullptr, nullptr};
@@ -46,11 +61,12 @@ struct jpg_ctx {
     int t_pending = 0;
     double t_total_ms = 0.0;
     uint64_t t_count = 0;
-    DevStatus *h_status = nullptr;  // pinned copy of eb.status
     int16_t *h_dc = nullptr;        // pinned
-    uint64_t nbits = 0;
-    size_t scan_len = 0;
 };
+
+static inline jpg_ctx::Slot &S(jpg_ctx *c) { return c->slot[c->cur]; }          // being written
+static inline const jpg_ctx::Slot &S(const jpg_ctx *c) { return c->slot[c->cur]; }
+static inline jpg_ctx::Slot &V(jpg_ctx *c) { return c->slot[c->view]; }         // being read
 
 #define HIP_TRY(ctx, expr)                   \
     do {                                     \
@@ -91,11 +107,17 @@ static int use_device(jpg_ctx *c) {
     return JPG_OK;
 }
 
+static int sync_all(jpg_ctx *c) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->stream_b) HIP_TRY(c, hipStreamSynchronize(c->stream_b));
+    return JPG_OK;
+}
+
 template <class T>
 static int grow(jpg_ctx *c, T *&p, size_t &cap, size_t need_elems) {
     if (need_elems <= cap && p) return JPG_OK;
     if (p) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (int e = sync_all(c)) return e;
         HIP_TRY(c, hipFree(p));
         p = nullptr;
         cap = 0;
@@ -130,22 +152,24 @@ extern "C" int jpg_create(jpg_ctx **out, int device, int dct_algo, int ra, int r
     jpg_ctx *c = new (std::nothrow) jpg_ctx();
     if (!c) return JPG_ERR_NOMEM;
     c->device = device; c->algo = dct_algo; c->h = h; c->v = v;
+    // (stream priorities were tried for the two streams and made no difference)
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipHostMalloc((void **)&c->h_status, sizeof(DevStatus), hipHostMallocDefault) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking) == hipSuccess &&
               hipHostMalloc((void **)&c->h_dc, 4 * sizeof(int16_t), hipHostMallocDefault) == hipSuccess &&
-              hipMalloc((void **)&c->d_dc, 4 * sizeof(int16_t)) == hipSuccess &&
-              hipMalloc((void **)&c->eb.status, sizeof(DevStatus)) == hipSuccess &&
-              hipMemset(c->eb.status, 0, sizeof(DevStatus)) == hipSuccess;
+              hipMalloc((void **)&c->d_dc, 4 * sizeof(int16_t)) == hipSuccess;
+    for (jpg_ctx::Slot &sl : c->slot) {
+        ok = ok && hipHostMalloc((void **)&sl.h_status, sizeof(DevStatus), hipHostMallocDefault) == hipSuccess &&
+             hipMalloc((void **)&sl.eb.status, sizeof(DevStatus)) == hipSuccess &&
+             hipMemset(sl.eb.status, 0, sizeof(DevStatus)) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.e_done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.s_done, hipEventDisableTiming) == hipSuccess;
+        if (ok) memset(sl.h_status, 0, sizeof(DevStatus));
 #ifdef JPG_TRACE
-    if (ok) ok = hipMalloc((void **)&c->eb.trace, 4096 * 8 * sizeof(unsigned long long)) == hipSuccess &&
-                 hipMemset(c->eb.trace, 0, 4096 * 8 * sizeof(unsigned long long)) == hipSuccess;
+        ok = ok && hipMalloc((void **)&sl.eb.trace, 4096 * 8 * sizeof(unsigned long long)) == hipSuccess &&
+             hipMemset(sl.eb.trace, 0, 4096 * 8 * sizeof(unsigned long long)) == hipSuccess;
 #endif
-    if (ok) {
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-        c->eb.stuff_grid = (size_t)cus * 2;
-        if (const char *ev = getenv("JPG_STUFF_GRID")) c->eb.stuff_grid = (size_t)atoi(ev) > 0 ? (size_t)atoi(ev) : c->eb.stuff_grid;
+        if (const char *ev = getenv("JPG_STUFF_GRID")) sl.eb.stuff_grid = (size_t)(atoi(ev) > 0 ? atoi(ev) : 0);
     }
     if (!ok) {
         (void)hipGetLastError();
@@ -160,20 +184,29 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
     void *dev[] = {c->d_src_own, c->d_plane[0], c->d_plane[1], c->d_plane[2], c->d_down[0], c->d_down[1], c->d_coef,
-                   c->d_tmp16, c->d_dc, c->eb.clen, c->eb.sparse, c->eb.status,
-                   c->eb.bits, c->eb.sagg, c->eb.sgrp, c->eb.shyp, c->eb.scan, c->eb.trace};
+                   c->d_tmp16, c->d_dc};
     for (void *p : dev)
         if (p) (void)hipFree(p);
+    for (jpg_ctx::Slot &sl : c->slot) {
+        void *sdev[] = {sl.eb.clen, sl.eb.sparse, sl.eb.status, sl.eb.bits, sl.eb.sagg, sl.eb.sgrp, sl.eb.shyp,
+                        sl.eb.scan, sl.eb.trace};
+        for (void *p : sdev)
+            if (p) (void)hipFree(p);
+        if (sl.h_status) (void)hipHostFree(sl.h_status);
+        if (sl.e_done) (void)hipEventDestroy(sl.e_done);
+        if (sl.s_done) (void)hipEventDestroy(sl.s_done);
+    }
     for (hipEvent_t e : c->t_ev)
         if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; k++) {
         if (c->h_bounce[k]) (void)hipHostFree(c->h_bounce[k]);
         if (c->bounce_done[k]) (void)hipEventDestroy(c->bounce_done[k]);
     }
-    if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_dc) (void)hipHostFree(c->h_dc);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     delete c;
 }
 
@@ -182,8 +215,7 @@ extern "C" void *jpg_stream(jpg_ctx *c) { return c ? (void *)c->stream : nullptr
 extern "C" int jpg_sync(jpg_ctx *c) {
     if (!c) return JPG_ERR_BAD_ARG;
     if (int e = use_device(c)) return e;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return JPG_OK;
+    return sync_all(c);
 }
 
 // JpegImage::new's dimension arithmetic (src/jpeg/jpeg_image.rs:36-56)
@@ -218,7 +250,7 @@ template <class T>
 static int regrow(jpg_ctx *c, T *&p, size_t n) {
     size_t cap = 0;
     if (p) {
-        (void)hipStreamSynchronize(c->stream);
+        if (int e = sync_all(c)) return e;
         (void)hipFree(p);
         p = nullptr;
     }
@@ -226,35 +258,37 @@ static int regrow(jpg_ctx *c, T *&p, size_t n) {
 }
 
 static int ensure_entropy(jpg_ctx *c) {
+    jpg_ctx::Slot &sl = S(c);
     const size_t nblk = (size_t)c->g.nblocks;
     const size_t nchunks = (nblk + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
     if ((nchunks + 63) / 64 > (size_t)MAX_GROUPS) return JPG_ERR_CAPACITY;
-    c->eb.nchunks = (long long)nchunks;
-    if (nblk <= c->ent_cap) return JPG_OK;
-    c->ent_cap = 0;   // nothing is usable until every buffer below has been replaced
+    sl.eb.nchunks = (long long)nchunks;
+    if (nblk <= sl.ent_cap) return JPG_OK;
+    sl.ent_cap = 0;   // nothing is usable until every buffer below has been replaced
     const size_t bits_bytes = worst_bits_bytes(nblk);
     const size_t scan_bytes = 2 * bits_bytes + 16;
     const size_t nseg = bits_bytes / STUFF_SEG + 2;
     int e;
-    if ((e = regrow(c, c->eb.clen, (nchunks + 63) / 64 * 64))) return e;
-    if ((e = regrow(c, c->eb.sparse, nchunks * CHUNK_STRIDE_WORDS))) return e;
-    if ((e = regrow(c, c->eb.sagg, nseg))) return e;
-    if ((e = regrow(c, c->eb.sgrp, nseg / 64 + 1))) return e;
-    if ((e = regrow(c, c->eb.shyp, nseg / 4096 + 1))) return e;
-    c->eb.stuff_epoch = 0;   // forces the hand-off words to be cleared before first use
-    if ((e = regrow(c, c->eb.scan, scan_bytes))) return e;
-    c->eb.scan_cap = scan_bytes;
-    c->eb.nseg_cap = nseg;
-    c->ent_cap = nblk;
+    if ((e = regrow(c, sl.eb.clen, (nchunks + 63) / 64 * 64))) return e;
+    if ((e = regrow(c, sl.eb.sparse, nchunks * CHUNK_STRIDE_WORDS))) return e;
+    if ((e = regrow(c, sl.eb.sagg, nseg))) return e;
+    if ((e = regrow(c, sl.eb.sgrp, nseg / 64 + 1))) return e;
+    if ((e = regrow(c, sl.eb.shyp, nseg / 4096 + 1))) return e;
+    sl.eb.stuff_epoch = 0;   // forces the hand-off words to be cleared before first use
+    if ((e = regrow(c, sl.eb.scan, scan_bytes))) return e;
+    sl.eb.scan_cap = scan_bytes;
+    sl.eb.nseg_cap = nseg;
+    sl.ent_cap = nblk;
     return JPG_OK;
 }
 
 // the dense copy of the stream is only kept for the staged calls
 static int ensure_dense(jpg_ctx *c) {
+    jpg_ctx::Slot &sl = V(c);
     const size_t need = worst_bits_bytes((size_t)c->g.nblocks);
-    if (c->eb.bits && c->eb.bits_cap >= need) return JPG_OK;
-    if (int e = regrow(c, c->eb.bits, need / 4)) return e;
-    c->eb.bits_cap = need;
+    if (sl.eb.bits && sl.eb.bits_cap >= need) return JPG_OK;
+    if (int e = regrow(c, sl.eb.bits, need / 4)) return e;
+    sl.eb.bits_cap = need;
     return JPG_OK;
 }
 
@@ -437,49 +471,65 @@ extern "C" int jpg_front_time(jpg_ctx *c, double *total_ms, uint64_t *launches) 
     return JPG_OK;
 }
 
+// Queue the entropy kernel on `stream` into the slot c->cur.  The slot's previous stuffing kernel
+// (possibly on stream_b) must have finished with the chunks first.
 static int queue_entropy(jpg_ctx *c, const int16_t pred[3]) {
     if (int e = ensure_entropy(c)) return e;
+    jpg_ctx::Slot &sl = S(c);
+    if (sl.busy) HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.s_done, 0));
     // errors are tagged with a launch number; clear the word before the number repeats
-    if (c->eb.epoch >= (1u << 22)) {
-        HIP_TRY(c, hipMemsetAsync(c->eb.status, 0, sizeof(DevStatus), c->stream));
-        c->eb.epoch = 0;
+    if (sl.eb.epoch >= (1u << 22)) {
+        HIP_TRY(c, hipMemsetAsync(sl.eb.status, 0, sizeof(DevStatus), c->stream));
+        sl.eb.epoch = 0;
     }
-    c->eb.epoch++;
-    c->eb.host_status = c->h_status;
-    c->dense_valid = false;
+    sl.eb.epoch++;
+    sl.eb.host_status = sl.h_status;
+    sl.dense_valid = false;
+    c->view = c->cur;
     static const int16_t zero[3] = {0, 0, 0};   // src/jpeg/entropy_coding.rs:38-40
-    HIP_TRY(c, launch_entropy(c->g, c->d_coef, pred ? pred : zero, c->eb, c->stream));
+    HIP_TRY(c, launch_entropy(c->g, c->d_coef, pred ? pred : zero, sl.eb, c->stream));
     return JPG_OK;
 }
 
-// queue the stuffing kernel (new generation of its hand-off words per launch)
-static int queue_stuff(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, int is_last) {
-    if (c->eb.stuff_epoch == 0 || c->eb.stuff_epoch >= 16383) {
-        HIP_TRY(c, hipMemsetAsync(c->eb.sagg, 0, c->eb.nseg_cap * sizeof(uint64_t), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->eb.sgrp, 0, (c->eb.nseg_cap / 64 + 1) * sizeof(uint64_t), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->eb.shyp, 0, (c->eb.nseg_cap / 4096 + 1) * sizeof(uint64_t), c->stream));
-        c->eb.stuff_epoch = 0;
+// Queue the stuffing kernel of slot c->cur on stream `st` (new generation of its hand-off words per
+// launch).  On stream_b it starts when the slot's entropy kernel is done and leaves `stream` free
+// for the next image.
+static int queue_stuff(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t st) {
+    jpg_ctx::Slot &sl = S(c);
+    if (st != c->stream) {
+        HIP_TRY(c, hipEventRecord(sl.e_done, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(st, sl.e_done, 0));
     }
-    c->eb.stuff_epoch++;
-    c->eb.host_status = c->h_status;
-    HIP_TRY(c, launch_stuff(c->eb, bit_offset, head_bits, is_last, c->stream));
+    if (sl.eb.stuff_epoch == 0 || sl.eb.stuff_epoch >= 16383) {
+        HIP_TRY(c, hipMemsetAsync(sl.eb.sagg, 0, sl.eb.nseg_cap * sizeof(uint64_t), st));
+        HIP_TRY(c, hipMemsetAsync(sl.eb.sgrp, 0, (sl.eb.nseg_cap / 64 + 1) * sizeof(uint64_t), st));
+        HIP_TRY(c, hipMemsetAsync(sl.eb.shyp, 0, (sl.eb.nseg_cap / 4096 + 1) * sizeof(uint64_t), st));
+        sl.eb.stuff_epoch = 0;
+    }
+    sl.eb.stuff_epoch++;
+    sl.eb.host_status = sl.h_status;
+    HIP_TRY(c, launch_stuff(sl.eb, bit_offset, head_bits, is_last, st));
+    HIP_TRY(c, hipEventRecord(sl.s_done, st));
+    sl.busy = true;
     return JPG_OK;
 }
 
-// status word of the last launch: 0 or the jpg_status a kernel raised
-static int kernel_error(const jpg_ctx *c) {
-    const int v = -c->h_status->error;
-    if (v > 0 && (uint32_t)(v >> 8) == c->eb.epoch) return -(v & 0xff);
+// status word of a slot's last launch: 0 or the jpg_status a kernel raised
+static int kernel_error(const jpg_ctx::Slot &sl) {
+    const int v = -sl.h_status->error;
+    if (v > 0 && (uint32_t)(v >> 8) == sl.eb.epoch) return -(v & 0xff);
     return JPG_OK;
 }
 
-// gather the chunks into the dense stream (also reports nbits)
+// gather the chunks of the viewed slot into the dense stream (also reports nbits)
 static int make_dense(jpg_ctx *c) {
-    if (c->dense_valid) return JPG_OK;
+    jpg_ctx::Slot &sl = V(c);
+    if (sl.dense_valid) return JPG_OK;
     if (int e = ensure_dense(c)) return e;
-    HIP_TRY(c, launch_dense(c->eb, c->stream));
+    sl.eb.host_status = sl.h_status;
+    HIP_TRY(c, launch_dense(sl.eb, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->dense_valid = true;
+    sl.dense_valid = true;
     return JPG_OK;
 }
 
@@ -487,11 +537,13 @@ static int entropy_common(jpg_ctx *c, const int16_t *pred, uint64_t *nbits) {
     if (!c) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_COEF) return JPG_ERR_STATE;
     if (int e = use_device(c)) return e;
+    c->npend = 0;
     if (int e = queue_entropy(c, pred)) return e;
     if (int e = make_dense(c)) return e;
-    if (int ke = kernel_error(c)) return ke;
-    c->nbits = c->h_status->nbits;
-    if (nbits) *nbits = c->nbits;
+    jpg_ctx::Slot &sl = S(c);
+    if (int ke = kernel_error(sl)) return ke;
+    sl.nbits = sl.h_status->nbits;
+    if (nbits) *nbits = sl.nbits;
     c->stage = ST_BITS;
     return JPG_OK;
 }
@@ -504,22 +556,23 @@ extern "C" int jpg_entropy_stripe(jpg_ctx *c, const int16_t pred[3], uint64_t *n
 
 extern "C" int jpg_stream_tail(jpg_ctx *c, uint32_t *last32) {
     if (!c || !last32) return JPG_ERR_BAD_ARG;
-    if (c->stage < ST_BITS || c->pending) return JPG_ERR_STATE;
+    if (c->stage < ST_BITS || c->npend) return JPG_ERR_STATE;
     if (int e = use_device(c)) return e;
     if (int e = make_dense(c)) return e;
-    const uint64_t nbytes = (c->nbits + 7) >> 3;
+    const jpg_ctx::Slot &sl = V(c);
+    const uint64_t nbytes = (sl.nbits + 7) >> 3;
     const uint64_t take = nbytes < 5 ? nbytes : 5;   // 32 bits may straddle 5 bytes
     uint8_t b[8] = {0};
     if (take) {
-        HIP_TRY(c, hipMemcpyAsync(b, reinterpret_cast<const uint8_t *>(c->eb.bits) + (nbytes - take), take,
+        HIP_TRY(c, hipMemcpyAsync(b, reinterpret_cast<const uint8_t *>(sl.eb.bits) + (nbytes - take), take,
                                   hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     uint64_t v = 0;
     for (uint64_t i = 0; i < take; i++) v = (v << 8) | b[i];
-    const unsigned pad = (unsigned)(nbytes * 8 - c->nbits);   // zero bits after the stream in its last byte
+    const unsigned pad = (unsigned)(nbytes * 8 - sl.nbits);   // zero bits after the stream in its last byte
     v >>= pad;
-    *last32 = (uint32_t)(c->nbits >= 32 ? v : v & ((1ull << c->nbits) - 1));
+    *last32 = (uint32_t)(sl.nbits >= 32 ? v : v & ((1ull << sl.nbits) - 1));
     return JPG_OK;
 }
 
@@ -536,14 +589,15 @@ extern "C" int jpg_last_dc(jpg_ctx *c, int16_t dc[3]) {
 
 extern "C" int jpg_stitch(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, int is_last, size_t *len, uint8_t *tail) {
     if (!c) return JPG_ERR_BAD_ARG;
-    if (c->stage < ST_BITS) return JPG_ERR_STATE;
+    if (c->stage < ST_BITS || c->npend) return JPG_ERR_STATE;
     if (int e = use_device(c)) return e;
-    if (int e = queue_stuff(c, bit_offset, head_bits, is_last)) return e;
+    if (int e = queue_stuff(c, bit_offset, head_bits, is_last, c->stream)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (int ke = kernel_error(c)) return ke;
-    c->scan_len = (size_t)c->h_status->scan_bytes;
-    if (len) *len = c->scan_len;
-    if (tail) *tail = (uint8_t)c->h_status->tail;
+    jpg_ctx::Slot &sl = S(c);
+    if (int ke = kernel_error(sl)) return ke;
+    sl.scan_len = (size_t)sl.h_status->scan_bytes;
+    if (len) *len = sl.scan_len;
+    if (tail) *tail = (uint8_t)sl.h_status->tail;
     c->stage = ST_SCAN;
     return JPG_OK;
 }
@@ -574,41 +628,75 @@ extern "C" int jpg_front_host(jpg_ctx *c, const uint8_t *pixels, int32_t W, int3
     return JPG_OK;
 }
 
+// entropy coding on `stream`, stuffing on stream_b, into the slot the previous fused encode did not use
+static int queue_back_end(jpg_ctx *c) {
+    c->cur = (c->cur + 1) % jpg_ctx::NSLOT;
+    if (int e = queue_entropy(c, nullptr)) return e;
+    if (int e = queue_stuff(c, 0, 0, 1, c->stream_b)) return e;
+    if (c->npend == jpg_ctx::NSLOT) {   // the oldest queued result is overwritten unread, as documented
+        for (int k = 1; k < c->npend; k++) c->fifo[k - 1] = c->fifo[k];
+        c->npend--;
+    }
+    c->fifo[c->npend++] = c->cur;
+    return JPG_OK;
+}
+
 extern "C" int jpg_encode_device_async(jpg_ctx *c, const uint8_t *dev_pixels, int32_t W, int32_t H, uint32_t stride,
                                        int bottom_up) {
     if (int e = jpg_front_device(c, dev_pixels, W, H, stride, bottom_up)) return e;
-    if (int e = queue_entropy(c, nullptr)) return e;
-    if (int e = queue_stuff(c, 0, 0, 1)) return e;
-    c->pending = true;
+    return queue_back_end(c);
+}
+
+#ifdef JPG_TRACE
+static void print_trace(const jpg_ctx::Slot &sl) {
+    if (!sl.eb.trace || !getenv("JPG_TRACE_PRINT")) return;
+    static unsigned long long h[4096 * 8];
+    (void)hipMemcpy(h, sl.eb.trace, sizeof h, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull;
+    for (int b = 0; b < 512; b++)
+        if (h[b * 8] && h[b * 8] < t0) t0 = h[b * 8];
+    for (int b : {0, 1, 100, 200, 300, 395, 400, 511}) {
+        fprintf(stderr, "wg %3d:", b);
+        for (int k = 0; k < 8; k++) fprintf(stderr, " %6.2f", h[b * 8 + k] ? (double)(h[b * 8 + k] - t0) / 100.0 : -1.0);
+        fprintf(stderr, " us\n");
+    }
+}
+#endif
+
+// results of a finished slot
+static int report(jpg_ctx *c, int k, uint64_t *nbits, size_t *stuffed_len) {
+    jpg_ctx::Slot &sl = c->slot[k];
+    c->view = k;
+    if (int ke = kernel_error(sl)) return ke;
+    sl.nbits = sl.h_status->nbits;
+    sl.scan_len = (size_t)sl.h_status->scan_bytes;
+    if (nbits) *nbits = sl.nbits;
+    if (stuffed_len) *stuffed_len = sl.scan_len;
+    c->stage = ST_SCAN;
     return JPG_OK;
 }
 
 extern "C" int jpg_finish(jpg_ctx *c, uint64_t *nbits, size_t *stuffed_len) {
     if (!c) return JPG_ERR_BAD_ARG;
-    if (!c->pending) return JPG_ERR_STATE;
+    if (!c->npend) return JPG_ERR_STATE;
     if (int e = use_device(c)) return e;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->pending = false;
+    if (int e = sync_all(c)) return e;
+    c->npend = 0;
 #ifdef JPG_TRACE
-    if (c->eb.trace && getenv("JPG_TRACE_PRINT")) {
-        static unsigned long long h[4096 * 8];
-        (void)hipMemcpy(h, c->eb.trace, sizeof h, hipMemcpyDeviceToHost);
-        unsigned long long t0 = ~0ull;
-        for (int b = 0; b < 512; b++) if (h[b * 8] && h[b * 8] < t0) t0 = h[b * 8];
-        for (int b : {0, 1, 100, 200, 300, 395, 400, 511}) {
-            fprintf(stderr, "wg %3d:", b);
-            for (int k = 0; k < 8; k++) fprintf(stderr, " %6.2f", h[b * 8 + k] ? (double)(h[b * 8 + k] - t0) / 100.0 : -1.0);
-            fprintf(stderr, " us\n");
-        }
-    }
+    print_trace(S(c));
 #endif
-    if (int ke = kernel_error(c)) return ke;
-    c->nbits = c->h_status->nbits;
-    c->scan_len = (size_t)c->h_status->scan_bytes;
-    if (nbits) *nbits = c->nbits;
-    if (stuffed_len) *stuffed_len = c->scan_len;
-    c->stage = ST_SCAN;
-    return JPG_OK;
+    return report(c, c->cur, nbits, stuffed_len);
+}
+
+extern "C" int jpg_finish_next(jpg_ctx *c, uint64_t *nbits, size_t *stuffed_len) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (!c->npend) return JPG_ERR_STATE;
+    if (int e = use_device(c)) return e;
+    const int k = c->fifo[0];
+    HIP_TRY(c, hipEventSynchronize(c->slot[k].s_done));
+    for (int j = 1; j < c->npend; j++) c->fifo[j - 1] = c->fifo[j];
+    c->npend--;
+    return report(c, k, nbits, stuffed_len);
 }
 
 extern "C" int jpg_encode_scan(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride, int bottom_up,
@@ -621,18 +709,17 @@ extern "C" int jpg_encode_scan(jpg_ctx *c, const uint8_t *pixels, int32_t W, int
     if (int e = ensure_coef(c)) return e;
     if (int e = queue_front(c)) return e;
     c->stage = ST_COEF;
-    if (int e = queue_entropy(c, nullptr)) return e;
-    if (int e = queue_stuff(c, 0, 0, 1)) return e;
-    c->pending = true;
+    if (int e = queue_back_end(c)) return e;
     if (int e = jpg_finish(c, nullptr, nullptr)) return e;
+    const jpg_ctx::Slot &sl = V(c);
     void *host = nullptr;
-    hipError_t he = hipHostMalloc(&host, c->scan_len ? c->scan_len : 1, hipHostMallocDefault);
+    hipError_t he = hipHostMalloc(&host, sl.scan_len ? sl.scan_len : 1, hipHostMallocDefault);
     if (he != hipSuccess) { c->last_hip = (int)he; (void)hipGetLastError(); return JPG_ERR_NOMEM; }
-    he = hipMemcpyAsync(host, c->eb.scan, c->scan_len, hipMemcpyDeviceToHost, c->stream);
+    he = hipMemcpyAsync(host, sl.eb.scan, sl.scan_len, hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
     if (he != hipSuccess) { (void)hipHostFree(host); c->last_hip = (int)he; (void)hipGetLastError(); return JPG_ERR_HIP; }
     *stuffed = static_cast<uint8_t *>(host);
-    *len = c->scan_len;
+    *len = sl.scan_len;
     return JPG_OK;
 }
 
@@ -650,20 +737,20 @@ extern "C" void jpg_free(void *p) {
 }
 
 extern "C" const uint8_t *jpg_bits_device(jpg_ctx *c) {
-    if (!c || c->stage < ST_BITS || c->pending) return nullptr;
+    if (!c || c->stage < ST_BITS || c->npend) return nullptr;
     if (use_device(c) || make_dense(c)) return nullptr;
-    return reinterpret_cast<const uint8_t *>(c->eb.bits);
+    return reinterpret_cast<const uint8_t *>(V(c).eb.bits);
 }
-extern "C" const uint8_t *jpg_scan_device(jpg_ctx *c) { return c && c->stage >= ST_SCAN ? c->eb.scan : nullptr; }
+extern "C" const uint8_t *jpg_scan_device(jpg_ctx *c) { return c && c->stage >= ST_SCAN ? V(c).eb.scan : nullptr; }
 
 extern "C" int jpg_get_bits(jpg_ctx *c, uint8_t *out, size_t cap) {
     if (!c || !out) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_BITS) return JPG_ERR_STATE;
-    const size_t n = (size_t)((c->nbits + 7) >> 3);
+    const size_t n = (size_t)((V(c).nbits + 7) >> 3);
     if (cap < n) return JPG_ERR_CAPACITY;
     if (int e = use_device(c)) return e;
     if (int e = make_dense(c)) return e;
-    HIP_TRY(c, hipMemcpyAsync(out, c->eb.bits, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, V(c).eb.bits, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return JPG_OK;
 }
@@ -671,9 +758,10 @@ extern "C" int jpg_get_bits(jpg_ctx *c, uint8_t *out, size_t cap) {
 extern "C" int jpg_get_scan(jpg_ctx *c, uint8_t *out, size_t cap) {
     if (!c || !out) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_SCAN) return JPG_ERR_STATE;
-    if (cap < c->scan_len) return JPG_ERR_CAPACITY;
+    const jpg_ctx::Slot &sl = V(c);
+    if (cap < sl.scan_len) return JPG_ERR_CAPACITY;
     if (int e = use_device(c)) return e;
-    HIP_TRY(c, hipMemcpyAsync(out, c->eb.scan, c->scan_len, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, sl.eb.scan, sl.scan_len, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return JPG_OK;
 }

@@ -131,6 +131,12 @@ class Encoder:
         self._ck(self._L.jpg_finish(self._ctx, C.byref(nbits), C.byref(n)))
         return nbits.value, n.value
 
+    def finish_next(self):
+        """Wait for the oldest of (up to two) queued encodes only: (nbits, stuffed length)."""
+        nbits, n = C.c_uint64(), C.c_size_t()
+        self._ck(self._L.jpg_finish_next(self._ctx, C.byref(nbits), C.byref(n)))
+        return nbits.value, n.value
+
     def encode_scan(self, rows, width, height, stride=None, bottom_up=True):
         """Host rows -> stuffed scan bytes (numpy uint8)."""
         rows = np.ascontiguousarray(rows, np.uint8)

@@ -353,3 +353,37 @@ def test_kernel_time_stamps(J):
     enc.encode_device_async(t.data_ptr(), w, h, rows.shape[1], True)
     enc.finish()
     assert enc.front_time() == (0.0, 0)
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_pipelined_encodes_keep_their_results(J, oracle, depth):
+    """Several encodes in flight on one context (stuffing on a second stream, rotating output
+    buffers): every image comes out byte-exact, in order, whatever the sizes."""
+    import torch
+    rng = np.random.default_rng(depth)
+    jobs = []
+    for i in range(9):
+        w, h = int(rng.integers(2, 40)) * 16, int(rng.integers(2, 30)) * 16
+        rows = J.host.synth_bgr(w, h, seed=100 + i, noise_only=bool(i % 3 == 0))
+        jobs.append((w, h, rows, torch.from_numpy(rows).cuda()))
+    torch.cuda.synchronize()
+    enc = J.Encoder((4, 2, 0), "bin-dct")
+    got, inflight = [], 0
+    for w, h, rows, t in jobs:
+        if inflight == depth:
+            nbits, n = enc.finish_next()
+            got.append((nbits, enc.scan(n)))
+            inflight -= 1
+        enc.encode_device_async(t.data_ptr(), w, h, rows.shape[1], True)
+        inflight += 1
+    while inflight:
+        nbits, n = enc.finish_next()
+        got.append((nbits, enc.scan(n)))
+        inflight -= 1
+    assert len(got) == len(jobs)
+    for (w, h, rows, _), (nbits, scan) in zip(jobs, got):
+        ref = _ref(oracle, rows, w, h, (4, 2, 0), "bin-dct")
+        assert nbits == ref.bits()[1]
+        np.testing.assert_array_equal(scan, ref.stuffed_scan())
+    with pytest.raises(J.JpgError):
+        enc.finish_next()                                       # nothing queued
