@@ -4,14 +4,16 @@
     python bench.py --gpus N --steps K --warmup W
 
 Workload: 7680x4320 24-bit BMP rows, 4:2:0, real-dct (the configuration the headline metric is quoted on).
-One step = every rank encodes its own batch of `--batch` distinct synthetic
-8K images (device-resident BMP rows -> stuffed JPEG scan bytes in HBM): colour
+One step = every rank encodes its own batch of `--batch` synthetic 8K images
+(device-resident BMP rows -> stuffed JPEG scan bytes in HBM): colour
 conversion + subsampling + DCT + quantisation (one fused kernel), entropy
-coding and byte stuffing.  Images are independent, so ranks share nothing
-(weak scaling, no data-path collective).  Prints ONE JSON line on rank 0.
+coding and byte stuffing, one launch of each kernel for the whole batch, and
+every image's result is taken at the end of the step.  Images are independent,
+so ranks share nothing (weak scaling, no data-path collective).  Prints ONE
+JSON line on rank 0.
 
-The batch rotates over distinct images so that the inputs of consecutive
-encodes do not sit in the 256 MiB Infinity Cache.
+The batch (1.6 GB of pixels) is far larger than the 256 MiB Infinity Cache, so
+no input is served from cache.
 """
 import argparse
 import json
@@ -34,12 +36,19 @@ def parse():
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--ratio", default="4:2:0")
     ap.add_argument("--dct-algorithm", default="real-dct")
-    ap.add_argument("--batch", type=int, default=4, help="distinct images per rank per step")
+    ap.add_argument("--batch", type=int, default=16, help="images per rank per step")
+    ap.add_argument("--distinct", type=int, default=4,
+                    help="images synthesised from scratch; the others are shifted copies of them at other addresses")
+    ap.add_argument("--isolated", action="store_true",
+                    help="also time back-to-back launches of the front kernel alone (single images)")
     ap.add_argument("--contexts", type=int, default=1,
                     help="encoder contexts (each with its own stream and buffers) the batch alternates over; "
                          "2 overlaps the tail of one encode with the front kernel of the next (higher MP/s, but "
                          "the kernels then share the device and their individual durations grow)")
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2, 3], help="encodes in flight per context")
+    ap.add_argument("--per-launch", type=int, default=0,
+                    help="images per launch set (jpg_encode_batch_device_async); 0 = the whole batch of the step, "
+                         "1 = one launch set per image")
     ap.add_argument("--time-every", type=int, default=16,
                     help="take the start/end time stamps of every n-th front-kernel launch of the timed region "
                          "(roofline figure); a stamped launch costs some host time, hence the sampling")
@@ -108,9 +117,17 @@ def main():
     stride = J.host.bmp_stride(W)
     # distinct images per rank: seed = config << 32 | image index
     imgs = []
+    base = []
     for i in range(args.batch):
-        rows = J.host.synth_bgr(W, H, seed=(3 << 32) | (rank * args.batch + i), noise_only=args.noise)
+        if i < max(1, args.distinct):
+            rows = J.host.synth_bgr(W, H, seed=(3 << 32) | (rank * args.batch + i), noise_only=args.noise)
+            base.append(rows)
+        else:
+            # the same picture shifted by a multiple of 16 pixels: different bytes at every address, same statistics
+            b = base[i % len(base)]
+            rows = np.ascontiguousarray(np.roll(b, 48 * (i // len(base)), axis=1))
         imgs.append(torch.from_numpy(rows).cuda())
+    del base
     torch.cuda.synchronize()
 
     # independent images overlap across contexts: the latency-bound tail of one encode
@@ -118,17 +135,25 @@ def main():
     encs = [J.Encoder(ratio, args.dct_algorithm, device=local) for _ in range(max(1, args.contexts))]
     enc = encs[0]
 
+    per_launch = args.per_launch if args.per_launch > 0 else args.batch
+    per_launch = min(per_launch, enc.max_batch())
+    groups = [imgs[i:i + per_launch] for i in range(0, len(imgs), per_launch)]
+
     def step():
-        # every image's result is taken (sizes read back) before its buffers are reused; a context keeps
-        # up to two encodes in flight, so the stuffing of one image overlaps the front kernel of the next
+        # Every image's result is taken (sizes read back) before its buffers are reused.  The images of a
+        # group go through one launch of each kernel; a context keeps up to `depth` groups in flight, so the
+        # stuffing of one group overlaps the front kernel of the next.
         res = None
         inflight = [0] * len(encs)
-        for i, t in enumerate(imgs):
+        for i, g in enumerate(groups):
             k = i % len(encs)
             if inflight[k] == args.depth:
                 res = encs[k].finish_next()
                 inflight[k] -= 1
-            encs[k].encode_device_async(t.data_ptr(), W, H, stride, True)
+            if len(g) == 1:
+                encs[k].encode_device_async(g[0].data_ptr(), W, H, stride, True)
+            else:
+                encs[k].encode_batch_device_async([t.data_ptr() for t in g], W, H, stride, True)
             inflight[k] += 1
         for k, e in enumerate(encs):
             while inflight[k]:
@@ -148,18 +173,19 @@ def main():
 
     for e in encs:
         # time stamps of every n-th front-kernel launch of the timed region (at least four samples)
-        e.set_timing(max(1, min(args.time_every, args.steps * args.batch // (4 * len(encs)))))
+        e.set_timing(max(1, min(args.time_every, args.steps * len(groups) // (4 * len(encs)))))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nbits, scan_len = step()
     barrier()
     dt = time.perf_counter() - t0
-    region_ms, region_n = 0.0, 0
+    region_ms, region_n, region_images = 0.0, 0, 0
     for e in encs:
-        ms, n = e.front_time()
+        ms, n, im = e.front_time()
         region_ms += ms
         region_n += n
+        region_images += im
         e.set_timing(0)
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -169,30 +195,36 @@ def main():
     # ---- roofline of the dominant kernel: fused colour+subsample+DCT+quant ----
     roof = None
     if rank == 0:
-        s = torch.cuda.ExternalStream(enc.stream, device=torch.device("cuda", local))
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for k in range(4):
-            enc.front_device(imgs[k % len(imgs)].data_ptr(), W, H, stride, True)
-        enc.sync()
-        n = args.kernel_iters
         kms = None
-        for rep in range(3):          # average launch duration of the steadiest of three back-to-back series
-            ev0.record(s)
-            for k in range(n):
+        if args.isolated:
+            s = torch.cuda.ExternalStream(enc.stream, device=torch.device("cuda", local))
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for k in range(4):
                 enc.front_device(imgs[k % len(imgs)].data_ptr(), W, H, stride, True)
-            ev1.record(s)
             enc.sync()
-            t = ev0.elapsed_time(ev1) / n
-            kms = t if kms is None else min(kms, t)
-        alg = enc.front_bytes()
-        # the figure of record: average duration of the launches inside the timed region
+            n = args.kernel_iters
+            for rep in range(3):          # average launch duration of the steadiest of three back-to-back series
+                ev0.record(s)
+                for k in range(n):
+                    enc.front_device(imgs[k % len(imgs)].data_ptr(), W, H, stride, True)
+                ev1.record(s)
+                enc.sync()
+                t = ev0.elapsed_time(ev1) / n
+                kms = t if kms is None else min(kms, t)
+        alg_image = enc.front_bytes()
+        # the figure of record: average duration of the launches inside the timed region (a launch covers
+        # images_per_launch images, so its algorithmic bytes are that many times an image's)
         rms = region_ms / max(region_n, 1)
+        ipl = region_images / max(region_n, 1)
+        alg = int(alg_image * ipl)
         achieved = alg / (rms * 1e-3) / 1e9
         workload = "%dx%d %s %s" % (W, H, args.ratio, args.dct_algorithm)
         roof = {"bound": "hbm", "kernel": "k_front", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(workload),
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (lambda t: int(t * ipl) if t else None)(pmc_traffic(workload)),
                 "algorithmic_bytes": alg, "kernel_ms": round(rms, 5), "launches_timed": region_n,
-                "isolated_kernel_ms": round(kms, 5)}
+                "images_per_launch": ipl}
+        if kms is not None:
+            roof["isolated_kernel_ms_per_image"] = round(kms, 5)
 
     if world > 1:
         dist.barrier()
@@ -213,7 +245,7 @@ def main():
             "dtype": "f32" if args.dct_algorithm.startswith("real") else "int32",
             "data": "synthetic" + (" (uniform noise)" if args.noise else ""),
             "config": {"workload": "%dx%d BMP, %s, %s" % (W, H, args.ratio, args.dct_algorithm),
-                       "images_per_rank_per_step": args.batch, "contexts_per_rank": len(encs), "encodes_in_flight_per_context": args.depth, "global_batch": args.batch * world,
+                       "images_per_rank_per_step": args.batch, "images_per_launch": per_launch, "contexts_per_rank": len(encs), "launch_sets_in_flight_per_context": args.depth, "global_batch": args.batch * world,
                        "parallelism": "image-sharded x%d" % world, "scan_bytes_last_image": int(scan_len),
                        "bits_per_pixel": round(nbits / (W * H), 4)},
             "roofline": roof,

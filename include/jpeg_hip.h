@@ -108,13 +108,27 @@ int jpg_front_host(jpg_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t h
  * stream without any host synchronisation.  jpg_finish() waits and reports. */
 int jpg_encode_device_async(jpg_ctx *ctx, const uint8_t *dev_pixels, int32_t width, int32_t height,
                             uint32_t row_stride, int bottom_up);
+/* ---- batches (no counterpart in the reference, which encodes one file per run) ----
+ * n (1..jpg_max_batch()) device-resident images of the same size, row stride and orientation go
+ * through ONE launch of each kernel, which removes the per-image launch and latency costs that
+ * dominate small images.  dev_pixels is a host array of n device pointers (rows dword-aligned).
+ * Queued like jpg_encode_device_async and retired with jpg_finish / jpg_finish_next, after which
+ * jpg_batch_result gives image i's bit count, stuffed length and the device address of its scan
+ * (valid as long as the results of that encode are), and jpg_get_batch_scan copies it out. */
+int jpg_max_batch(void);
+int jpg_encode_batch_device_async(jpg_ctx *ctx, const uint8_t *const *dev_pixels, int32_t n, int32_t width, int32_t height,
+                                  uint32_t row_stride, int bottom_up);
+int jpg_batch_result(jpg_ctx *ctx, int32_t i, uint64_t *nbits, size_t *stuffed_len, const uint8_t **scan_dev);
+int jpg_get_batch_scan(jpg_ctx *ctx, int32_t i, uint8_t *out, size_t cap);
+
 /* Measurement aid: with every = n > 0, every n-th fused front launch (jpg_front_device/_host,
  * jpg_encode_device_async, jpg_encode_scan) hands two events to the dispatch, which receive
  * the kernel's own start and end time stamps (0 switches it off); jpg_front_time waits for
- * the stream and returns the summed duration of those launches in milliseconds and their
- * number.  No counterpart in the reference. */
+ * the stream and returns the summed duration of those launches in milliseconds, their
+ * number and the number of images they covered (a batch is one launch).  No counterpart in
+ * the reference. */
 int jpg_set_timing(jpg_ctx *ctx, int every);
-int jpg_front_time(jpg_ctx *ctx, double *total_ms, uint64_t *launches);
+int jpg_front_time(jpg_ctx *ctx, double *total_ms, uint64_t *launches, uint64_t *images);
 /* Page-locked host memory (release with jpg_free).  Rows handed to jpg_load_bgr,
  * jpg_front_host or jpg_encode_scan from such memory are copied by DMA at full
  * link speed; ordinary (pageable) memory is staged through the library's own

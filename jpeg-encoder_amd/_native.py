@@ -17,7 +17,8 @@ DCT_REAL, DCT_BIN, DCT_REAL_STRICT = 0, 1, 2
 SYMBOLS = [
     "jpg_strerror", "jpg_last_hip_error", "jpg_create", "jpg_destroy", "jpg_stream", "jpg_sync",
     "jpg_load_bgr", "jpg_load_bgr_device", "jpg_downsample", "jpg_dct_quant", "jpg_entropy", "jpg_stuff",
-    "jpg_front_device", "jpg_front_host", "jpg_encode_device_async", "jpg_finish", "jpg_finish_next", "jpg_encode_scan", "jpg_set_timing", "jpg_front_time", "jpg_host_alloc", "jpg_free",
+    "jpg_front_device", "jpg_front_host", "jpg_encode_device_async", "jpg_finish", "jpg_finish_next", "jpg_max_batch", "jpg_encode_batch_device_async", "jpg_batch_result",
+    "jpg_get_batch_scan", "jpg_encode_scan", "jpg_set_timing", "jpg_front_time", "jpg_host_alloc", "jpg_free",
     "jpg_entropy_stripe", "jpg_stream_tail", "jpg_last_dc", "jpg_stitch", "jpg_bits_device", "jpg_scan_device",
     "jpg_get_bits", "jpg_get_scan", "jpg_plane_dims", "jpg_coeff_dims", "jpg_get_plane", "jpg_get_coeffs",
     "jpg_front_bytes", "jpg_num_blocks",
@@ -81,9 +82,13 @@ def lib():
     L.jpg_stuff.argtypes = [vp, szp]
     L.jpg_finish.argtypes = [vp, u64p, szp]
     L.jpg_finish_next.argtypes = [vp, u64p, szp]
+    L.jpg_max_batch.argtypes = []
+    L.jpg_encode_batch_device_async.argtypes = [vp, C.POINTER(vp), i32, i32, i32, u32, C.c_int]
+    L.jpg_batch_result.argtypes = [vp, i32, u64p, szp, C.POINTER(vp)]
+    L.jpg_get_batch_scan.argtypes = [vp, i32, vp, C.c_size_t]
     L.jpg_encode_scan.argtypes = [vp, vp, i32, i32, u32, C.c_int, C.POINTER(vp), szp]
     L.jpg_set_timing.argtypes = [vp, C.c_int]
-    L.jpg_front_time.argtypes = [vp, C.POINTER(C.c_double), u64p]
+    L.jpg_front_time.argtypes = [vp, C.POINTER(C.c_double), u64p, u64p]
     L.jpg_host_alloc.argtypes = [C.c_size_t]
     L.jpg_host_alloc.restype = vp
     L.jpg_free.argtypes = [vp]

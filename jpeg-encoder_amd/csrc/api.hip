@@ -36,8 +36,9 @@ struct jpg_ctx {
     // front and entropy kernels of the next image run on `stream` into the other set.
     struct Slot {
         EntropyBufs eb{};
-        size_t ent_cap = 0;             // in blocks
-        DevStatus *h_status = nullptr;  // pinned copy of eb.status
+        const uint8_t **d_srcs = nullptr; size_t cap_srcs = 0;   // device array of a batch's pixel pointers
+        size_t cap_clen = 0, cap_sparse = 0, cap_scan = 0, cap_status = 0, cap_sagg = 0, cap_sgrp = 0, cap_shyp = 0;
+        DevStatus *h_status = nullptr;  // [cap_status] pinned copy of eb.status
         hipEvent_t e_done = nullptr;    // entropy kernel finished (recorded on stream)
         hipEvent_t s_done = nullptr;    // stuffing kernel finished (recorded on the stream it ran on)
         bool busy = false;              // s_done has been recorded at least once
@@ -45,6 +46,7 @@ struct jpg_ctx {
         uint64_t nbits = 0;
         size_t scan_len = 0;
     } slot[NSLOT];
+    int nimg = 1;                // images of the current geometry (a batch), set with the geometry
     int cur = 0;                 // slot of the most recent entropy launch
     int view = 0;                // slot whose results the getters show
     int fifo[NSLOT] = {};        // slots of queued fused encodes that jpg_finish_next has not handed out yet
@@ -60,7 +62,8 @@ struct jpg_ctx {
     hipEvent_t t_ev[2 * TIMING_RING] = {};
     int t_pending = 0;
     double t_total_ms = 0.0;
-    uint64_t t_count = 0;
+    uint64_t t_count = 0, t_images = 0;
+    int t_imgs[TIMING_RING] = {};   // images of each pending launch
     int16_t *h_dc = nullptr;        // pinned
 };
 
@@ -159,12 +162,8 @@ extern "C" int jpg_create(jpg_ctx **out, int device, int dct_algo, int ra, int r
               hipHostMalloc((void **)&c->h_dc, 4 * sizeof(int16_t), hipHostMallocDefault) == hipSuccess &&
               hipMalloc((void **)&c->d_dc, 4 * sizeof(int16_t)) == hipSuccess;
     for (jpg_ctx::Slot &sl : c->slot) {
-        ok = ok && hipHostMalloc((void **)&sl.h_status, sizeof(DevStatus), hipHostMallocDefault) == hipSuccess &&
-             hipMalloc((void **)&sl.eb.status, sizeof(DevStatus)) == hipSuccess &&
-             hipMemset(sl.eb.status, 0, sizeof(DevStatus)) == hipSuccess &&
-             hipEventCreateWithFlags(&sl.e_done, hipEventDisableTiming) == hipSuccess &&
+        ok = ok && hipEventCreateWithFlags(&sl.e_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&sl.s_done, hipEventDisableTiming) == hipSuccess;
-        if (ok) memset(sl.h_status, 0, sizeof(DevStatus));
 #ifdef JPG_TRACE
         ok = ok && hipMalloc((void **)&sl.eb.trace, 4096 * 8 * sizeof(unsigned long long)) == hipSuccess &&
              hipMemset(sl.eb.trace, 0, 4096 * 8 * sizeof(unsigned long long)) == hipSuccess;
@@ -190,7 +189,7 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
     for (void *p : dev)
         if (p) (void)hipFree(p);
     for (jpg_ctx::Slot &sl : c->slot) {
-        void *sdev[] = {sl.eb.clen, sl.eb.sparse, sl.eb.status, sl.eb.bits, sl.eb.sagg, sl.eb.sgrp, sl.eb.shyp,
+        void *sdev[] = {sl.d_srcs, sl.eb.clen, sl.eb.sparse, sl.eb.status, sl.eb.bits, sl.eb.sagg, sl.eb.sgrp, sl.eb.shyp,
                         sl.eb.scan, sl.eb.trace};
         for (void *p : sdev)
             if (p) (void)hipFree(p);
@@ -231,12 +230,13 @@ static int set_geometry(jpg_ctx *c, int32_t W, int32_t H, uint32_t stride, int b
     g.stride = stride; g.bottom_up = bottom_up ? 1 : 0;
     g.nblocks = (long long)g.mcux * g.mcuy * g.nb;
     c->g = g;
+    c->nimg = 1;
     c->stage = ST_NONE; c->have_planes = false; c->down_done = false;
     return JPG_OK;
 }
 
 static int ensure_coef(jpg_ctx *c) {
-    const size_t nblk = (size_t)c->g.nblocks;
+    const size_t nblk = (size_t)c->g.nblocks * (size_t)(c->nimg > 0 ? c->nimg : 1);
     return grow(c, c->d_coef, c->coef_cap, nblk * 64);
 }
 
@@ -257,28 +257,45 @@ static int regrow(jpg_ctx *c, T *&p, size_t n) {
     return grow(c, p, cap, n);
 }
 
+// back-end buffers of the slot being written, for c->nimg images of the current geometry
 static int ensure_entropy(jpg_ctx *c) {
     jpg_ctx::Slot &sl = S(c);
+    const size_t nimg = (size_t)(c->nimg > 0 ? c->nimg : 1);
     const size_t nblk = (size_t)c->g.nblocks;
     const size_t nchunks = (nblk + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
     if ((nchunks + 63) / 64 > (size_t)MAX_GROUPS) return JPG_ERR_CAPACITY;
-    sl.eb.nchunks = (long long)nchunks;
-    if (nblk <= sl.ent_cap) return JPG_OK;
-    sl.ent_cap = 0;   // nothing is usable until every buffer below has been replaced
+    const size_t cstride = (nchunks + 63) / 64 * 64;
     const size_t bits_bytes = worst_bits_bytes(nblk);
-    const size_t scan_bytes = 2 * bits_bytes + 16;
+    const size_t scan_stride = (2 * bits_bytes + 16 + 255) / 256 * 256;
     const size_t nseg = bits_bytes / STUFF_SEG + 2;
+    sl.eb.nimg = (int)nimg;
+    sl.eb.nchunks = (long long)nchunks;
+    sl.eb.cstride = (long long)cstride;
     int e;
-    if ((e = regrow(c, sl.eb.clen, (nchunks + 63) / 64 * 64))) return e;
-    if ((e = regrow(c, sl.eb.sparse, nchunks * CHUNK_STRIDE_WORDS))) return e;
-    if ((e = regrow(c, sl.eb.sagg, nseg))) return e;
-    if ((e = regrow(c, sl.eb.sgrp, nseg / 64 + 1))) return e;
-    if ((e = regrow(c, sl.eb.shyp, nseg / 4096 + 1))) return e;
-    sl.eb.stuff_epoch = 0;   // forces the hand-off words to be cleared before first use
-    if ((e = regrow(c, sl.eb.scan, scan_bytes))) return e;
-    sl.eb.scan_cap = scan_bytes;
-    sl.eb.nseg_cap = nseg;
-    sl.ent_cap = nblk;
+    if ((e = grow(c, sl.eb.clen, sl.cap_clen, nimg * cstride))) return e;
+    if ((e = grow(c, sl.eb.sparse, sl.cap_sparse, nimg * cstride * CHUNK_STRIDE_WORDS))) return e;
+    if ((e = grow(c, sl.eb.scan, sl.cap_scan, nimg * scan_stride))) return e;
+    sl.eb.scan_stride = scan_stride;
+    if (nimg > sl.cap_status) {
+        if ((e = sync_all(c))) return e;
+        if (sl.eb.status) (void)hipFree(sl.eb.status);
+        if (sl.h_status) (void)hipHostFree(sl.h_status);
+        sl.eb.status = nullptr; sl.h_status = nullptr; sl.cap_status = 0;
+        HIP_TRY(c, hipMalloc((void **)&sl.eb.status, nimg * sizeof(DevStatus)));
+        HIP_TRY(c, hipMemset(sl.eb.status, 0, nimg * sizeof(DevStatus)));
+        HIP_TRY(c, hipHostMalloc((void **)&sl.h_status, nimg * sizeof(DevStatus), hipHostMallocDefault));
+        memset(sl.h_status, 0, nimg * sizeof(DevStatus));
+        sl.cap_status = nimg;
+        sl.eb.epoch = 0;
+    }
+    // the hand-off words are laid out per image with the stride nseg: a change of either relocates them
+    if (nseg != sl.eb.nseg_cap || nimg * nseg > sl.cap_sagg) {
+        if ((e = grow(c, sl.eb.sagg, sl.cap_sagg, nimg * nseg))) return e;
+        if ((e = grow(c, sl.eb.sgrp, sl.cap_sgrp, nimg * (nseg / 64 + 1)))) return e;
+        if ((e = grow(c, sl.eb.shyp, sl.cap_shyp, nimg * (nseg / 4096 + 1)))) return e;
+        sl.eb.nseg_cap = nseg;
+        sl.eb.stuff_epoch = 0;   // forces the hand-off words to be cleared before first use
+    }
     return JPG_OK;
 }
 
@@ -425,15 +442,17 @@ static int harvest_timing(jpg_ctx *c) {
         HIP_TRY(c, hipEventElapsedTime(&ms, c->t_ev[2 * k], c->t_ev[2 * k + 1]));
         c->t_total_ms += ms;
         c->t_count++;
+        c->t_images += (uint64_t)c->t_imgs[k];
     }
     c->t_pending = 0;
     return JPG_OK;
 }
 
-// the fused front kernel, with its start and end time stamps taken when timing is on
-static int queue_front(jpg_ctx *c) {
+// the fused front kernel (for one image, or for the batch srcs[0..n-1]), with its start and end
+// time stamps taken when timing is on
+static int queue_front(jpg_ctx *c, const uint8_t *const *srcs = nullptr, int n = 1) {
     if (!c->timing || (c->t_seen++ % (uint64_t)c->timing) != 0) {
-        HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream));
+        HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream, nullptr, nullptr, srcs, n));
         return JPG_OK;
     }
     if (c->t_pending == jpg_ctx::TIMING_RING) {
@@ -444,7 +463,8 @@ static int queue_front(jpg_ctx *c) {
     if (!e0) HIP_TRY(c, hipEventCreate(&e0));
     if (!e1) HIP_TRY(c, hipEventCreate(&e1));
     // the events take the dispatch's own time stamps: no extra packets in the stream
-    HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream, e0, e1));
+    HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream, e0, e1, srcs, n));
+    c->t_imgs[c->t_pending] = n;
     c->t_pending++;
     return JPG_OK;
 }
@@ -456,18 +476,20 @@ extern "C" int jpg_set_timing(jpg_ctx *c, int every) {
     c->t_pending = 0;
     c->t_total_ms = 0.0;
     c->t_count = 0;
+    c->t_images = 0;
     c->t_seen = 0;
     c->timing = every > 0 ? every : 0;
     return JPG_OK;
 }
 
-extern "C" int jpg_front_time(jpg_ctx *c, double *total_ms, uint64_t *launches) {
+extern "C" int jpg_front_time(jpg_ctx *c, double *total_ms, uint64_t *launches, uint64_t *images) {
     if (!c) return JPG_ERR_BAD_ARG;
     if (int e = use_device(c)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (int e = harvest_timing(c)) return e;
     if (total_ms) *total_ms = c->t_total_ms;
     if (launches) *launches = c->t_count;
+    if (images) *images = c->t_images;
     return JPG_OK;
 }
 
@@ -479,7 +501,7 @@ static int queue_entropy(jpg_ctx *c, const int16_t pred[3]) {
     if (sl.busy) HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.s_done, 0));
     // errors are tagged with a launch number; clear the word before the number repeats
     if (sl.eb.epoch >= (1u << 22)) {
-        HIP_TRY(c, hipMemsetAsync(sl.eb.status, 0, sizeof(DevStatus), c->stream));
+        HIP_TRY(c, hipMemsetAsync(sl.eb.status, 0, sl.cap_status * sizeof(DevStatus), c->stream));
         sl.eb.epoch = 0;
     }
     sl.eb.epoch++;
@@ -501,9 +523,9 @@ static int queue_stuff(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, int i
         HIP_TRY(c, hipStreamWaitEvent(st, sl.e_done, 0));
     }
     if (sl.eb.stuff_epoch == 0 || sl.eb.stuff_epoch >= 16383) {
-        HIP_TRY(c, hipMemsetAsync(sl.eb.sagg, 0, sl.eb.nseg_cap * sizeof(uint64_t), st));
-        HIP_TRY(c, hipMemsetAsync(sl.eb.sgrp, 0, (sl.eb.nseg_cap / 64 + 1) * sizeof(uint64_t), st));
-        HIP_TRY(c, hipMemsetAsync(sl.eb.shyp, 0, (sl.eb.nseg_cap / 4096 + 1) * sizeof(uint64_t), st));
+        HIP_TRY(c, hipMemsetAsync(sl.eb.sagg, 0, sl.cap_sagg * sizeof(uint64_t), st));
+        HIP_TRY(c, hipMemsetAsync(sl.eb.sgrp, 0, sl.cap_sgrp * sizeof(uint64_t), st));
+        HIP_TRY(c, hipMemsetAsync(sl.eb.shyp, 0, sl.cap_shyp * sizeof(uint64_t), st));
         sl.eb.stuff_epoch = 0;
     }
     sl.eb.stuff_epoch++;
@@ -516,8 +538,10 @@ static int queue_stuff(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, int i
 
 // status word of a slot's last launch: 0 or the jpg_status a kernel raised
 static int kernel_error(const jpg_ctx::Slot &sl) {
-    const int v = -sl.h_status->error;
-    if (v > 0 && (uint32_t)(v >> 8) == sl.eb.epoch) return -(v & 0xff);
+    for (int i = 0; i < (sl.eb.nimg > 0 ? sl.eb.nimg : 1); i++) {
+        const int v = -sl.h_status[i].error;
+        if (v > 0 && (uint32_t)(v >> 8) == sl.eb.epoch) return -(v & 0xff);
+    }
     return JPG_OK;
 }
 
@@ -645,6 +669,54 @@ extern "C" int jpg_encode_device_async(jpg_ctx *c, const uint8_t *dev_pixels, in
                                        int bottom_up) {
     if (int e = jpg_front_device(c, dev_pixels, W, H, stride, bottom_up)) return e;
     return queue_back_end(c);
+}
+
+// ---- batches of equally sized images: one launch of each kernel for all of them ----
+
+extern "C" int jpg_max_batch(void) { return 64; }
+
+extern "C" int jpg_encode_batch_device_async(jpg_ctx *c, const uint8_t *const *dev_pixels, int32_t n, int32_t W, int32_t H,
+                                             uint32_t stride, int bottom_up) {
+    if (!c || !dev_pixels || n < 1 || n > jpg_max_batch()) return JPG_ERR_BAD_ARG;
+    if (int e = use_device(c)) return e;
+    if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
+    if ((int64_t)c->g.nblocks * n >= (1LL << 31)) return JPG_ERR_CAPACITY;
+    // a batch is read in place: rows must be dword-aligned (single images are re-pitched instead)
+    if (stride & 3) return JPG_ERR_BAD_ARG;
+    for (int i = 0; i < n; i++)
+        if (!dev_pixels[i] || (reinterpret_cast<uintptr_t>(dev_pixels[i]) & 3)) return JPG_ERR_BAD_ARG;
+    c->nimg = n;
+    c->d_src = dev_pixels[0];
+    jpg_ctx::Slot &next = c->slot[(c->cur + 1) % jpg_ctx::NSLOT];   // the slot queue_back_end is about to use
+    if (int e = grow(c, next.d_srcs, next.cap_srcs, (size_t)n)) return e;
+    HIP_TRY(c, hipMemcpyAsync(next.d_srcs, dev_pixels, (size_t)n * sizeof(uint8_t *), hipMemcpyHostToDevice, c->stream));
+    if (int e = ensure_coef(c)) return e;
+    if (int e = queue_front(c, next.d_srcs, n)) return e;
+    c->stage = ST_COEF;
+    return queue_back_end(c);
+}
+
+extern "C" int jpg_batch_result(jpg_ctx *c, int32_t i, uint64_t *nbits, size_t *stuffed_len, const uint8_t **scan_dev) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_SCAN) return JPG_ERR_STATE;
+    const jpg_ctx::Slot &sl = V(c);
+    if (i < 0 || i >= (sl.eb.nimg > 0 ? sl.eb.nimg : 1)) return JPG_ERR_BAD_ARG;
+    if (nbits) *nbits = sl.h_status[i].nbits;
+    if (stuffed_len) *stuffed_len = (size_t)sl.h_status[i].scan_bytes;
+    if (scan_dev) *scan_dev = sl.eb.scan + (size_t)i * sl.eb.scan_stride;
+    return JPG_OK;
+}
+
+extern "C" int jpg_get_batch_scan(jpg_ctx *c, int32_t i, uint8_t *out, size_t cap) {
+    if (!c || !out) return JPG_ERR_BAD_ARG;
+    size_t len = 0;
+    const uint8_t *src = nullptr;
+    if (int e = jpg_batch_result(c, i, nullptr, &len, &src)) return e;
+    if (cap < len) return JPG_ERR_CAPACITY;
+    if (int e = use_device(c)) return e;
+    HIP_TRY(c, hipMemcpyAsync(out, src, len, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return JPG_OK;
 }
 
 #ifdef JPG_TRACE

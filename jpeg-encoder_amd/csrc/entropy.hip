@@ -53,13 +53,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 
 struct EntArgs {
     const int16_t *coef;
-    long long nblocks, nchunks;
+    long long nblocks, nchunks;   // per image
+    int nimg;                // images in this launch (their blocks follow each other in coef)
+    long long cstride;       // chunk slots per image in clen / sparse (>= nchunks)
     int nb, hv;
     int16_t pred[3];
     uint32_t epoch;          // tags errors (see raise_error)
-    uint32_t *clen;          // [nchunks] out: bits of each chunk
-    uint32_t *sparse;        // [nchunks][CHUNK_STRIDE_WORDS] out: the chunk's bits, MSB first in each word
-    DevStatus *status;
+    uint32_t *clen;          // [nimg][cstride] out: bits of each chunk
+    uint32_t *sparse;        // [nimg][cstride][CHUNK_STRIDE_WORDS] out: the chunk's bits, MSB first in each word
+    DevStatus *status;       // [nimg]
 };
 
 // Errors are recorded as -(epoch << 8 | code) with atomicMin, so a newer launch always
@@ -297,10 +299,10 @@ __device__ __forceinline__ uint32_t mod_small(uint32_t x, uint32_t nb, uint32_t 
 // pieces per lane) into R0..R7 and, for the few blocks whose DC predecessor lies before the chunk,
 // that DC into PDC.  Branch-free (addresses are clamped instead) so that the loads can stay in
 // flight across the coding of the previous chunk.
-#define JPG_CHUNK_LOAD(CH, FM, R, PDC)                                                              \
+#define JPG_CHUNK_LOAD(COEF, LC, FM, R, PDC)                                                        \
     do {                                                                                            \
-        const long long first_ = (CH) * CHUNK_BLOCKS;                                               \
-        const uint4 *src_ = reinterpret_cast<const uint4 *>(a.coef);                                \
+        const long long first_ = (LC) * CHUNK_BLOCKS;                                               \
+        const uint4 *src_ = reinterpret_cast<const uint4 *>(COEF);                                  \
         R##0 = src_[min(first_ * 8 + 0 * 64 + lane, last_piece)];                                   \
         R##1 = src_[min(first_ * 8 + 1 * 64 + lane, last_piece)];                                   \
         R##2 = src_[min(first_ * 8 + 2 * 64 + lane, last_piece)];                                   \
@@ -312,11 +314,14 @@ __device__ __forceinline__ uint32_t mod_small(uint32_t x, uint32_t nb, uint32_t 
         const int jb_ = (int)mod_small((FM) + lane, a.nb, magic);                                   \
         const long long prev_ = first_ + lane - prev_distance(jb_, a.nb, a.hv);                     \
         /* lanes that need nothing from outside read the chunk's first line, loaded anyway */       \
-        PDC = a.coef[((prev_ >= 0 && prev_ < first_) ? prev_ : min(first_, a.nblocks - 1)) * 64];   \
+        PDC = (COEF)[((prev_ >= 0 && prev_ < first_) ? prev_ : min(first_, a.nblocks - 1)) * 64];   \
     } while (0)
 
 // Persistent: a wave takes chunks blockIdx.x * ENT_WAVES + wave, + gridDim.x * ENT_WAVES, ...
+// BATCH: the chunks of nimg equally sized images are numbered through (image i has chunks
+// i * nchunks .. (i + 1) * nchunks - 1); every image starts its own DC predictor chains.
 // (LDS limits a SIMD to 3 waves, so the register budget may be spent on keeping the prefetch in registers)
+template <bool BATCH>
 __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 3))) void k_entropy(EntArgs a) {
     __shared__ uint32_t sLut[LUT_WORDS];
     __shared__ __attribute__((aligned(16))) uint8_t sCoef[ENT_WAVES][CHUNK_BLOCKS * SLOT_BYTES];
@@ -325,13 +330,28 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long stride = (long long)gridDim.x * ENT_WAVES;
     long long chunk = (long long)blockIdx.x * ENT_WAVES + wave;
+    const long long total_chunks = a.nchunks * a.nimg;
     const uint32_t magic = (65536u + a.nb - 1) / a.nb;            // x / nb == (x * magic) >> 16 for small x
-    uint32_t fm = (uint32_t)((chunk * CHUNK_BLOCKS) % a.nb);      // first block of the chunk within its MCU
     const uint32_t fm_step = (uint32_t)((stride * CHUNK_BLOCKS) % a.nb);
     const long long last_piece = a.nblocks * 8 - 1;
+    // image, chunk inside the image and (first block of the chunk) mod nb, for chunk number c
+    long long img, lc;
+    uint32_t fm;
+    auto locate = [&](long long c) {
+        if (BATCH) {
+            img = c / a.nchunks;
+            lc = c - img * a.nchunks;
+            fm = (uint32_t)(lc * CHUNK_BLOCKS) % (uint32_t)a.nb;  // (a batch image has fewer than 2^31 blocks)
+        } else {
+            img = 0;
+            lc = c;
+        }
+    };
+    if (!BATCH) fm = (uint32_t)((chunk * CHUNK_BLOCKS) % a.nb);
+    locate(min(chunk, total_chunks - 1));
     uint4 pre0, pre1, pre2, pre3, pre4, pre5, pre6, pre7;   // (an array would be kept in scratch memory)
     int pre_pdc;
-    JPG_CHUNK_LOAD(min(chunk, a.nchunks - 1), fm, pre, pre_pdc);
+    JPG_CHUNK_LOAD(a.coef + img * a.nblocks * 64, lc, fm, pre, pre_pdc);
 
     for (int i = tid; i < LUT_WORDS; i += ENT_THREADS) sLut[i] = (&HUFF_DEV.e[0][0])[i];
     __syncthreads();
@@ -339,9 +359,11 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     uint8_t *coefs = sCoef[wave];
     uint32_t *out = sOut[wave];
     const uint16_t *slot = reinterpret_cast<const uint16_t *>(&coefs[lane * SLOT_BYTES]);
-    for (; chunk < a.nchunks; chunk += stride) {
-        const long long first = chunk * CHUNK_BLOCKS;
+    for (; chunk < total_chunks; chunk += stride) {
+        const long long first = lc * CHUNK_BLOCKS;                // within the image
         const int nvalid = (int)min((long long)CHUNK_BLOCKS, a.nblocks - first);
+        const long long slot_index = img * a.cstride + lc;        // where the chunk's results go
+        DevStatus *status = a.status + img;
 
         // stage the chunk's coefficients, one padded slot per block
         {
@@ -360,8 +382,9 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         const int pdc_outside = pre_pdc;
         const uint32_t fm_now = fm;
         // the next chunk's loads fly while this one is coded
-        fm = mod_small(fm + fm_step, a.nb, magic);
-        JPG_CHUNK_LOAD(min(chunk + stride, a.nchunks - 1), fm, pre, pre_pdc);
+        if (!BATCH) fm = mod_small(fm + fm_step, a.nb, magic);
+        locate(min(chunk + stride, total_chunks - 1));
+        JPG_CHUNK_LOAD(a.coef + img * a.nblocks * 64, lc, fm, pre, pre_pdc);
         __builtin_amdgcn_wave_barrier();
 
         const bool valid = lane < nvalid;
@@ -391,14 +414,14 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
 
         // 1. lengths
         AccWriter acc;                                            // blocks of up to ACC_BITS bits are kept whole
-        const uint32_t len = valid ? code_block(slot, mlo, mhi, dc_diff, lut, a.status, a.epoch, acc) : 0u;
+        const uint32_t len = valid ? code_block(slot, mlo, mhi, dc_diff, lut, status, a.epoch, acc) : 0u;
         const uint32_t sc = wave_incl_scan(len);                  // bits up to and including this lane's block
         const uint32_t total = __shfl(sc, 63);
-        if (lane == 0) a.clen[chunk] = total;
+        if (lane == 0) a.clen[slot_index] = total;
 
         // 2. code and store; a chunk too long for the LDS window goes in several passes, each
         // starting in the word the previous one ended in (that word is carried over and stored again)
-        uint32_t *dst = a.sparse + (size_t)chunk * CHUNK_STRIDE_WORDS;
+        uint32_t *dst = a.sparse + (size_t)slot_index * CHUNK_STRIDE_WORDS;
         constexpr uint32_t WINDOW = OUT_WORDS * 32;               // bits per pass
         uint32_t done = 0;                                        // bits of the chunk already stored
         uint32_t carry = 0;                                       // the bits before `done` in its word
@@ -417,7 +440,7 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
                 } else {                                          // long block: walk it again
                     BitWriter w;
                     w.init(out, pos);
-                    code_block(slot, mlo, mhi, dc_diff, lut, a.status, a.epoch, w);
+                    code_block(slot, mlo, mhi, dc_diff, lut, status, a.epoch, w);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -435,9 +458,14 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
 struct StreamArgs {
     const uint32_t *sparse;  // chunk slots written by k_entropy
     const uint32_t *clen;    // bits per chunk
-    long long nchunks;
-    int ngroups;             // groups of 64 chunks (<= MAX_GROUPS)
-    DevStatus *status;       // nbits, scan_bytes and tail out
+    long long nchunks;       // per image
+    int ngroups;             // groups of 64 chunks of an image (<= MAX_GROUPS)
+    // a batch: image i is handled by workgroups i * wpi .. (i + 1) * wpi - 1 and owns a stride of each array
+    int wpi;
+    long long cstride;       // chunk slots per image in sparse / clen
+    size_t out_stride;       // bytes per image in `out`
+    size_t agg_stride, grp_stride, hyp_stride;   // words per image in agg / grp / hyp
+    DevStatus *status;       // [nimg] nbits, scan_bytes and tail out
     uint32_t shift;          // place the stream `shift` (0..7) bits later
     uint32_t head;           // bits OR-ed into the first byte (top `shift` bits)
     int is_last;             // keep the trailing partial byte
@@ -445,7 +473,7 @@ struct StreamArgs {
     uint32_t epoch;          // generation of those words
     uint32_t err_epoch;      // epoch errors are tagged with (that of the entropy launch)
     uint8_t *out;            // stuffed bytes, or the dense stream for k_stream<false>
-    DevStatus *host_status;  // pinned host copy, filled at the end (may be null)
+    DevStatus *host_status;  // [nimg] pinned host copy, filled at the end (may be null)
     unsigned long long *trace;  // debug builds only
 };
 
@@ -483,7 +511,7 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 #ifdef JPG_TRACE
-// debug build: wall-clock stamps (100 MHz) of the phases of the first pass of every workgroup
+// debug build: wall-clock stamps (100 MHz) of the phases of the first pass of every workgroup (single images)
 // (kept in registers and stored at the end of the first pass, so that the stores do not perturb the phases)
 #define JPG_STAMP(K) do { stamps[K] = wall_clock64(); if ((K) == 7 && threadIdx.x == 0 && a.trace && !stamped) { \
         for (int k_ = 0; k_ < 8; k_++) a.trace[blockIdx.x * 8 + k_] = stamps[k_]; stamped = true; } } while (0)
@@ -508,6 +536,18 @@ static_assert(SEG_WORDS == WPT * ST_THREADS && ST_THREADS >= TABLE, "whole words
 // instruction count of every step small (a lone wave issues an instruction only every ~5 ns).
 template <bool STUFF>
 __global__ __launch_bounds__(ST_THREADS) void k_stream(StreamArgs a) {
+    {   // this workgroup's image: from here on `a` describes that image alone
+        const int img = blockIdx.x / a.wpi;
+        a.sparse += (size_t)img * a.cstride * CHUNK_STRIDE_WORDS;
+        a.clen += img * a.cstride;
+        a.out += img * a.out_stride;
+        a.agg += img * a.agg_stride;
+        a.grp += img * a.grp_stride;
+        a.hyp += img * a.hyp_stride;
+        a.status += img;
+        if (a.host_status) a.host_status += img;
+    }
+    const unsigned wg = blockIdx.x % a.wpi, nwg = a.wpi;   // position among the workgroups of the image
     extern __shared__ uint64_t sG[];     // [ngroups + 1] bits before each group of 64 chunks
     __shared__ uint64_t sPart[ST_WAVES];
     __shared__ int sT[TABLE + 1];          // chunk offsets relative to the segment's first bit
@@ -575,7 +615,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_stream(StreamArgs a) {
     const uint64_t nloop = nseg ? nseg : 1;          // the tail of an empty stripe still has to be reported
     const Sums sums{a.agg, a.grp, a.hyp, a.epoch, (long long)nseg};
 
-    for (uint64_t seg = blockIdx.x; seg < nloop; seg += gridDim.x) {
+    for (uint64_t seg = wg; seg < nloop; seg += nwg) {
         // ---- offsets of the chunks under this segment (first TABLE threads)
         const long long P0 = (long long)seg * SEG_BITS - (long long)a.shift;   // stream position of the segment's first bit
         const uint64_t p0 = P0 > 0 ? (uint64_t)P0 : 0;
@@ -767,6 +807,8 @@ __global__ __launch_bounds__(ST_THREADS) void k_stream(StreamArgs a) {
 hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred[3], const EntropyBufs &b,
                           hipStream_t s) {
     const long long nchunks = (g.nblocks + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
+    const int nimg = b.nimg > 0 ? b.nimg : 1;
+    if (nchunks != b.nchunks || b.cstride < nchunks || (nimg > 1 && g.nblocks >= (1LL << 31))) return hipErrorInvalidValue;
     // as many workgroups as fit on the device at once (each loops over its share of the chunks)
     static long long resident_cache[64] = {};
     int dev = 0;
@@ -776,26 +818,26 @@ hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred
     if (resident == 0) {
         int cus = 0, per_cu = 0;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_entropy, ENT_THREADS, 0);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_entropy<false>, ENT_THREADS, 0);
         if (e != hipSuccess) return e;
         resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
         if (dev >= 0 && dev < 64) resident_cache[dev] = resident;
     }
-    const unsigned grid = (unsigned)min((nchunks + ENT_WAVES - 1) / ENT_WAVES, resident);
-    EntArgs a{coef, g.nblocks, nchunks, g.nb, g.h * g.v, {pred[0], pred[1], pred[2]}, b.epoch, b.clen, b.sparse, b.status};
-    hipLaunchKernelGGL(k_entropy, dim3(grid), dim3(ENT_THREADS), 0, s, a);
+    const unsigned grid = (unsigned)min((nchunks * nimg + ENT_WAVES - 1) / ENT_WAVES, resident);
+    EntArgs a{coef, g.nblocks, nchunks, nimg, b.cstride, g.nb, g.h * g.v, {pred[0], pred[1], pred[2]}, b.epoch, b.clen,
+              b.sparse, b.status};
+    if (nimg > 1) hipLaunchKernelGGL(k_entropy<true>, dim3(grid), dim3(ENT_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_entropy<false>, dim3(grid), dim3(ENT_THREADS), 0, s, a);
     return hipGetLastError();
 }
 
-static StreamArgs stream_args(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, uint8_t *out) {
-    return StreamArgs{b.sparse, b.clen, b.nchunks, (int)((b.nchunks + 63) / 64), b.status, (uint32_t)(bit_offset & 7),
-                      head_bits, is_last, b.sagg, b.sgrp, b.shyp, b.stuff_epoch, b.epoch, out, b.host_status, b.trace};
-}
-
 template <bool STUFF>
-static hipError_t launch_stream(const EntropyBufs &b, StreamArgs a, hipStream_t s) {
-    if (a.ngroups > MAX_GROUPS || !a.out) return hipErrorInvalidValue;
-    const size_t lds = (a.ngroups + 1) * sizeof(uint64_t);
+static hipError_t launch_stream(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, uint8_t *out,
+                                size_t out_stride, hipStream_t s) {
+    const int nimg = b.nimg > 0 ? b.nimg : 1;
+    const int ngroups = (int)((b.nchunks + 63) / 64);
+    if (ngroups > MAX_GROUPS || !out) return hipErrorInvalidValue;
+    const size_t lds = (ngroups + 1) * sizeof(uint64_t);
     // no more workgroups than fit on the device at once: a segment waits for the segments before it, which
     // must therefore be running or finished whatever the dispatch order
     static long long resident_cache[2][64] = {};
@@ -816,17 +858,26 @@ static hipError_t launch_stream(const EntropyBufs &b, StreamArgs a, hipStream_t 
     }
     size_t cap = (size_t)resident;
     if (b.stuff_grid && b.stuff_grid < cap) cap = b.stuff_grid;
-    const unsigned grid = (unsigned)(b.nseg_cap < cap ? (b.nseg_cap ? b.nseg_cap : 1) : cap);
-    hipLaunchKernelGGL(k_stream<STUFF>, dim3(grid), dim3(ST_THREADS), lds, s, a);
+    if ((size_t)nimg > cap) return hipErrorInvalidValue;       // the caller splits larger batches
+    size_t wpi = cap / nimg;                                     // workgroups per image
+    if (wpi > b.nseg_cap) wpi = b.nseg_cap ? b.nseg_cap : 1;
+    StreamArgs a{b.sparse, b.clen, b.nchunks, ngroups, (int)wpi, b.cstride, out_stride, b.nseg_cap, b.nseg_cap / 64 + 1,
+                 b.nseg_cap / 4096 + 1, b.status, (uint32_t)(bit_offset & 7), head_bits, is_last, b.sagg, b.sgrp, b.shyp,
+                 b.stuff_epoch, b.epoch, out, b.host_status, b.trace};
+    hipLaunchKernelGGL(k_stream<STUFF>, dim3((unsigned)(wpi * nimg)), dim3(ST_THREADS), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s) {
-    return launch_stream<true>(b, stream_args(b, bit_offset, head_bits, is_last, b.scan), s);
+    return launch_stream<true>(b, bit_offset, head_bits, is_last, b.scan, b.scan_stride, s);
 }
 
 hipError_t launch_dense(const EntropyBufs &b, hipStream_t s) {
-    return launch_stream<false>(b, stream_args(b, 0, 0, 1, reinterpret_cast<uint8_t *>(b.bits)), s);
+    if ((b.nimg > 0 ? b.nimg : 1) != 1) return hipErrorInvalidValue;   // single images only
+    return launch_stream<false>(b, 0, 0, 1, reinterpret_cast<uint8_t *>(b.bits), 0, s);
 }
+
+// most images one launch of the stream kernels can take
+int max_batch_images() { return 128; }
 
 }  // namespace jpg

@@ -82,9 +82,11 @@ __device__ __forceinline__ void store_chroma(uint8_t *sCb, uint8_t *sCr, int iy,
     }
 }
 
+// A batch of equally sized images is one launch: srcs[i] (when given) is the pixel array of image
+// i, whose tiles follow those of image i-1 in the grid and whose blocks follow in `coef`.
 template <int HS, int VS, int ALGO>
-__global__ __launch_bounds__(THREADS) void k_front(const uint8_t *__restrict__ src, Geom g,
-                                                   int16_t *__restrict__ coef) {
+__global__ __launch_bounds__(THREADS) void k_front(const uint8_t *__restrict__ src, const uint8_t *const *__restrict__ srcs,
+                                                   Geom g, int16_t *__restrict__ coef) {
     using C = TileCfg<HS, VS>;
     // Y plane, then Cb, Cr planes of the tile; phase B reuses the space for the finished blocks
     __shared__ __attribute__((aligned(16))) uint8_t lds[C::LDS_BYTES];
@@ -93,8 +95,16 @@ __global__ __launch_bounds__(THREADS) void k_front(const uint8_t *__restrict__ s
     uint8_t *sCr = sCb + 8 * C::CW;
 
     const int tiles_x = (g.mcux + C::MCUS - 1) / C::MCUS;
-    const int tile_x = blockIdx.x % tiles_x;
-    const int tile_y = blockIdx.x / tiles_x;
+    int tile = blockIdx.x;
+    if (srcs) {
+        const int per_image = tiles_x * g.mcuy;
+        const int img = tile / per_image;
+        tile -= img * per_image;
+        src = srcs[img];
+        coef += (size_t)img * (size_t)g.nblocks * 64;
+    }
+    const int tile_x = tile % tiles_x;
+    const int tile_y = tile / tiles_x;
     const int mcu0 = tile_x * C::MCUS;                        // first MCU column of the tile
     const int mcus = min(C::MCUS, g.mcux - mcu0);             // MCUs really present
     const int x0 = mcu0 * 8 * HS;
@@ -211,16 +221,18 @@ __global__ __launch_bounds__(THREADS) void k_front(const uint8_t *__restrict__ s
 
 // e0/e1 (both or neither): events that receive the kernel's own start and end time stamps
 template <int HS, int VS>
-static hipError_t launch_front_hv(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s,
-                                  hipEvent_t e0, hipEvent_t e1) {
+static hipError_t launch_front_hv(const Geom &g, int algo, const uint8_t *src, const uint8_t *const *srcs, int nimg,
+                                  int16_t *coef, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     using C = TileCfg<HS, VS>;
     const int tiles_x = (g.mcux + C::MCUS - 1) / C::MCUS;
-    const dim3 grid((unsigned)(tiles_x * g.mcuy)), block(THREADS);
+    const long long tiles = (long long)tiles_x * g.mcuy * nimg;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)tiles), block(THREADS);
     switch (algo) {
-        case ALGO_REAL: hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, src, g, coef); break;
-        case ALGO_BIN: hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, src, g, coef); break;
+        case ALGO_REAL: hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, src, srcs, g, coef); break;
+        case ALGO_BIN: hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, src, srcs, g, coef); break;
         case ALGO_REAL_STRICT:
-            hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_REAL_STRICT>), grid, block, 0, s, e0, e1, 0, src, g, coef);
+            hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_REAL_STRICT>), grid, block, 0, s, e0, e1, 0, src, srcs, g, coef);
             break;
         default: return hipErrorInvalidValue;
     }
@@ -228,12 +240,13 @@ static hipError_t launch_front_hv(const Geom &g, int algo, const uint8_t *src, i
 }
 
 hipError_t launch_front(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s, hipEvent_t e0,
-                        hipEvent_t e1) {
-    // the fast path reads rows as dwords
-    if ((reinterpret_cast<uintptr_t>(src) & 3) || (g.stride & 3)) return hipErrorInvalidValue;
-    if (g.h == 2 && g.v == 2) return launch_front_hv<2, 2>(g, algo, src, coef, s, e0, e1);
-    if (g.h == 2 && g.v == 1) return launch_front_hv<2, 1>(g, algo, src, coef, s, e0, e1);
-    if (g.h == 1 && g.v == 1) return launch_front_hv<1, 1>(g, algo, src, coef, s, e0, e1);
+                        hipEvent_t e1, const uint8_t *const *srcs, int nimg) {
+    // the fast path reads rows as dwords (the caller checks the pointers of a batch)
+    if ((!srcs && (reinterpret_cast<uintptr_t>(src) & 3)) || (g.stride & 3) || nimg < 1) return hipErrorInvalidValue;
+    if (!srcs) nimg = 1;
+    if (g.h == 2 && g.v == 2) return launch_front_hv<2, 2>(g, algo, src, srcs, nimg, coef, s, e0, e1);
+    if (g.h == 2 && g.v == 1) return launch_front_hv<2, 1>(g, algo, src, srcs, nimg, coef, s, e0, e1);
+    if (g.h == 1 && g.v == 1) return launch_front_hv<1, 1>(g, algo, src, srcs, nimg, coef, s, e0, e1);
     return hipErrorInvalidValue;
 }
 

@@ -51,30 +51,35 @@ struct DevStatus {
 };
 
 struct EntropyBufs {
-    long long nchunks;     // chunks of the current image
-    uint32_t *clen;        // [nchunks] bits of each chunk
-    uint32_t *sparse;      // [nchunks][CHUNK_STRIDE_WORDS] coded bits of each chunk, MSB first in each word
+    int nimg;              // images of the current launch (a batch of equally sized images), >= 1
+    long long nchunks;     // chunks of one image
+    long long cstride;     // chunk slots per image in clen / sparse (nchunks rounded up to 64)
+    uint32_t *clen;        // [nimg][cstride] bits of each chunk
+    uint32_t *sparse;      // [nimg][cstride][CHUNK_STRIDE_WORDS] coded bits of each chunk, MSB first in each word
     uint32_t epoch;        // tags the error word of the current entropy launch (host side, 1..2^22)
-    DevStatus *status;
-    DevStatus *host_status;  // pinned host copy the last kernel fills (may be null)
+    DevStatus *status;       // [nimg]
+    DevStatus *host_status;  // [nimg] pinned host copy the last kernel fills (may be null)
     uint32_t *bits;        // dense unstuffed MSB-first stream in memory byte order (staged API only, may be null)
     size_t bits_cap;       // bytes
     // running sums of the 0xFF counts of the stuffing segments (see entropy.hip); each word is
     // {epoch:14 | valid:1 | value:49} written by one 8-byte store
-    uint64_t *sagg;        // [nseg] 0xFF bytes of the segment
-    uint64_t *sgrp;        // [nseg/64] ... of a group of 64 segments
-    uint64_t *shyp;        // [nseg/4096] ... of a hyper-group of 64 groups
+    uint64_t *sagg;        // [nimg][nseg_cap] 0xFF bytes of the segment
+    uint64_t *sgrp;        // [nimg][nseg_cap/64 + 1] ... of a group of 64 segments
+    uint64_t *shyp;        // [nimg][nseg_cap/4096 + 1] ... of a hyper-group of 64 groups
     uint32_t stuff_epoch;  // their generation (1..16383)
     size_t stuff_grid;     // workgroups of the stream kernels (all must be able to be resident)
-    uint8_t *scan;         // stuffed stream
-    size_t scan_cap;
-    size_t nseg_cap;
+    uint8_t *scan;         // [nimg][scan_stride] stuffed streams
+    size_t scan_stride;    // bytes per image
+    size_t nseg_cap;       // stuffing segments an image can have
     unsigned long long *trace;  // debug builds only (JPG_TRACE): phase stamps of the stream kernel
 };
 
-// e0/e1: optional events that receive the kernel's own start and end time stamps
+// e0/e1: optional events that receive the kernel's own start and end time stamps.
+// srcs/nimg: a batch of nimg equally sized images (device array of device pointers) in one launch;
+// their blocks follow each other in `coef`.
 hipError_t launch_front(const Geom &g, int algo, const uint8_t *src, int16_t *coef, hipStream_t s,
-                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, const uint8_t *const *srcs = nullptr,
+                        int nimg = 1);
 hipError_t launch_color(const Geom &g, const uint8_t *src, uint8_t *y, uint8_t *cb, uint8_t *cr, hipStream_t s);
 hipError_t launch_downsample(const Geom &g, const uint8_t *cb, const uint8_t *cr, uint8_t *cb_out, uint8_t *cr_out,
                              hipStream_t s);
@@ -89,5 +94,7 @@ hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s);
 // writes the dense stream to b.bits
 hipError_t launch_dense(const EntropyBufs &b, hipStream_t s);
+// most images one launch of the stream kernels can take
+int max_batch_images();
 
 }  // namespace jpg

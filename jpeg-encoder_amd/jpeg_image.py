@@ -131,6 +131,29 @@ class Encoder:
         self._ck(self._L.jpg_finish(self._ctx, C.byref(nbits), C.byref(n)))
         return nbits.value, n.value
 
+    def encode_batch_device_async(self, dev_ptrs, width, height, stride, bottom_up=True):
+        """Queue one launch set for len(dev_ptrs) equally sized device-resident images."""
+        n = len(dev_ptrs)
+        arr = (C.c_void_p * n)(*dev_ptrs)
+        self.width, self.height = width, height
+        self._ck(self._L.jpg_encode_batch_device_async(self._ctx, arr, n, width, height, stride, int(bottom_up)))
+
+    def batch_result(self, i):
+        """(nbits, stuffed length, device address of the scan) of image i of the retired batch."""
+        nbits, n, p = C.c_uint64(), C.c_size_t(), C.c_void_p()
+        self._ck(self._L.jpg_batch_result(self._ctx, i, C.byref(nbits), C.byref(n), C.byref(p)))
+        return nbits.value, n.value, p.value
+
+    def batch_scan(self, i):
+        _, n, _ = self.batch_result(i)
+        out = np.zeros(n, np.uint8)
+        if n:
+            self._ck(self._L.jpg_get_batch_scan(self._ctx, i, out.ctypes.data, out.nbytes))
+        return out
+
+    def max_batch(self):
+        return self._L.jpg_max_batch()
+
     def finish_next(self):
         """Wait for the oldest of (up to two) queued encodes only: (nbits, stuffed length)."""
         nbits, n = C.c_uint64(), C.c_size_t()
@@ -192,10 +215,10 @@ class Encoder:
         self._ck(self._L.jpg_set_timing(self._ctx, int(every)))
 
     def front_time(self):
-        """(summed milliseconds, number) of the bracketed front launches since set_timing."""
-        ms, n = C.c_double(), C.c_uint64()
-        self._ck(self._L.jpg_front_time(self._ctx, C.byref(ms), C.byref(n)))
-        return ms.value, n.value
+        """(summed milliseconds, launches, images) of the time-stamped front launches since set_timing."""
+        ms, n, im = C.c_double(), C.c_uint64(), C.c_uint64()
+        self._ck(self._L.jpg_front_time(self._ctx, C.byref(ms), C.byref(n), C.byref(im)))
+        return ms.value, n.value, im.value
 
     def front_bytes(self):
         return self._L.jpg_front_bytes(self._ctx)

@@ -347,12 +347,12 @@ def test_kernel_time_stamps(J):
     for _ in range(10):
         enc.encode_device_async(t.data_ptr(), w, h, rows.shape[1], True)
         enc.finish()
-    ms, n = enc.front_time()
-    assert n == 5 and 0.0005 < ms / n < 5.0
+    ms, n, images = enc.front_time()
+    assert n == 5 and images == 5 and 0.0005 < ms / n < 5.0
     enc.set_timing(0)
     enc.encode_device_async(t.data_ptr(), w, h, rows.shape[1], True)
     enc.finish()
-    assert enc.front_time() == (0.0, 0)
+    assert enc.front_time() == (0.0, 0, 0)
 
 
 @pytest.mark.parametrize("depth", [1, 2, 3])
@@ -387,3 +387,29 @@ def test_pipelined_encodes_keep_their_results(J, oracle, depth):
         np.testing.assert_array_equal(scan, ref.stuffed_scan())
     with pytest.raises(J.JpgError):
         enc.finish_next()                                       # nothing queued
+
+
+@pytest.mark.parametrize("ratio,algo,w,h,n", [((4, 2, 2), "bin-dct", 320, 200, 7), ((4, 2, 0), "bin-dct", 1920, 1080, 16),
+                                             ((4, 4, 4), "real-dct-strict", 100, 60, 64), ((4, 2, 0), "bin-dct", 48, 40, 1)])
+def test_batches_match_single_images(J, oracle, ratio, algo, w, h, n):
+    """n equally sized images through one launch of each kernel: every image byte-exact; pipelined batches too."""
+    import torch
+    imgs = [J.host.synth_bgr(w, h, seed=500 + i, noise_only=bool(i % 4 == 1)) for i in range(n)]
+    dev = [torch.from_numpy(r).cuda() for r in imgs]
+    torch.cuda.synchronize()
+    enc = J.Encoder(ratio, algo)
+    assert enc.max_batch() >= 64
+    ptrs = [t.data_ptr() for t in dev]
+    enc.encode_batch_device_async(ptrs, w, h, imgs[0].shape[1], True)
+    enc.encode_batch_device_async(ptrs[::-1], w, h, imgs[0].shape[1], True)     # a second batch in flight
+    refs = [_ref(oracle, r, w, h, ratio, "bin-dct" if algo == "bin-dct" else "real-dct") for r in imgs]
+    for order in (list(range(n)), list(range(n))[::-1]):
+        enc.finish_next()
+        for i, k in enumerate(order):
+            nbits, ln, ptr = enc.batch_result(i)
+            assert nbits == refs[k].bits()[1] and ptr
+            np.testing.assert_array_equal(enc.batch_scan(i), refs[k].stuffed_scan(), err_msg="image %d" % k)
+    # a single image afterwards on the same context
+    np.testing.assert_array_equal(enc.encode_scan(imgs[0], w, h), refs[0].stuffed_scan())
+    with pytest.raises(J.JpgError):
+        enc.encode_batch_device_async(ptrs * 80, w, h, imgs[0].shape[1], True)  # more than jpg_max_batch
