@@ -104,8 +104,14 @@ int jpg_front_device(jpg_ctx *ctx, const uint8_t *dev_pixels, int32_t width, int
  * is complete when the call returns, so `pixels` may be reused) */
 int jpg_front_host(jpg_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t height, uint32_t row_stride,
                    int bottom_up);
-/* jpg_front_device + entropy coding + stuffing, all queued on the context's
- * stream without any host synchronisation.  jpg_finish() waits and reports. */
+/* A whole encode from device-resident rows to the stuffed scan, queued without any host
+ * synchronisation; jpg_finish() waits and reports.  Images at least one tile (512 pixels) wide go
+ * through ONE kernel from pixels to Huffman-coded bits (no coefficient ever reaches memory) plus the
+ * stuffing kernel; narrower ones through the front kernel, the entropy kernel and the stuffing
+ * kernel (also for every image when the environment variable JPG_TWO_KERNELS=1 is set at
+ * jpg_create).  The bytes are the same either way.  After the single-kernel path jpg_get_coeffs,
+ * jpg_last_dc and jpg_entropy compute the coefficients on request when the context holds its own
+ * copy of the rows (host input), else they return JPG_ERR_STATE: call jpg_front_device for them. */
 int jpg_encode_device_async(jpg_ctx *ctx, const uint8_t *dev_pixels, int32_t width, int32_t height,
                             uint32_t row_stride, int bottom_up);
 /* ---- batches (no counterpart in the reference, which encodes one file per run) ----
@@ -121,8 +127,8 @@ int jpg_encode_batch_device_async(jpg_ctx *ctx, const uint8_t *const *dev_pixels
 int jpg_batch_result(jpg_ctx *ctx, int32_t i, uint64_t *nbits, size_t *stuffed_len, const uint8_t **scan_dev);
 int jpg_get_batch_scan(jpg_ctx *ctx, int32_t i, uint8_t *out, size_t cap);
 
-/* Measurement aid: with every = n > 0, every n-th fused front launch (jpg_front_device/_host,
- * jpg_encode_device_async, jpg_encode_scan) hands two events to the dispatch, which receive
+/* Measurement aid: with every = n > 0, every n-th launch of the front kernel or of the fused coding
+ * kernel (jpg_front_device/_host, jpg_encode_*) hands two events to the dispatch, which receive
  * the kernel's own start and end time stamps (0 switches it off); jpg_front_time waits for
  * the stream and returns the summed duration of those launches in milliseconds, their
  * number and the number of images they covered (a batch is one launch).  No counterpart in
@@ -199,6 +205,9 @@ int jpg_get_coeffs(jpg_ctx *ctx, int comp, int16_t *out, size_t cap);
 uint64_t jpg_front_bytes(const jpg_ctx *ctx);
 /* number of 8x8 blocks (all components) of the current image */
 uint64_t jpg_num_blocks(const jpg_ctx *ctx);
+/* 1 when whole encodes of the current image size run the single fused coding kernel (which reads
+ * row_stride*H bytes and writes only the coded bits), 0 when they run front + entropy kernels */
+int jpg_fused_coding(const jpg_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ SYMBOLS = [
     "jpg_get_batch_scan", "jpg_encode_scan", "jpg_set_timing", "jpg_front_time", "jpg_host_alloc", "jpg_free",
     "jpg_entropy_stripe", "jpg_stream_tail", "jpg_last_dc", "jpg_stitch", "jpg_bits_device", "jpg_scan_device",
     "jpg_get_bits", "jpg_get_scan", "jpg_plane_dims", "jpg_coeff_dims", "jpg_get_plane", "jpg_get_coeffs",
-    "jpg_front_bytes", "jpg_num_blocks",
+    "jpg_front_bytes", "jpg_num_blocks", "jpg_fused_coding",
 ]
 
 
@@ -111,6 +111,8 @@ def lib():
     L.jpg_front_bytes.restype = C.c_uint64
     L.jpg_num_blocks.argtypes = [vp]
     L.jpg_num_blocks.restype = C.c_uint64
+    L.jpg_fused_coding.argtypes = [vp]
+    L.jpg_fused_coding.restype = C.c_int
     _lib = L
     return L
 

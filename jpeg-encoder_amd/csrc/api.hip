@@ -29,6 +29,8 @@ struct jpg_ctx {
     uint8_t *d_plane[3] = {nullptr, nullptr, nullptr}; size_t plane_cap = 0;   // Wp x Hp each
     uint8_t *d_down[2] = {nullptr, nullptr}; size_t down_cap = 0;              // Wc x Hc each
     int16_t *d_coef = nullptr; size_t coef_cap = 0;                            // in blocks
+    bool coef_valid = false;    // d_coef holds the coefficients of the current image
+    bool two_kernels = false;   // JPG_TWO_KERNELS=1: whole encodes never use the fused coding kernel
     int16_t *d_tmp16 = nullptr; size_t tmp16_cap = 0;
     int16_t *d_dc = nullptr;     // last DCs out (3 values)
     static constexpr int NSLOT = 3;
@@ -170,6 +172,7 @@ extern "C" int jpg_create(jpg_ctx **out, int device, int dct_algo, int ra, int r
 #endif
         if (const char *ev = getenv("JPG_STUFF_GRID")) sl.eb.stuff_grid = (size_t)(atoi(ev) > 0 ? atoi(ev) : 0);
     }
+    if (const char *ev = getenv("JPG_TWO_KERNELS")) c->two_kernels = atoi(ev) != 0;
     if (!ok) {
         (void)hipGetLastError();
         jpg_destroy(c);
@@ -231,7 +234,7 @@ static int set_geometry(jpg_ctx *c, int32_t W, int32_t H, uint32_t stride, int b
     g.nblocks = (long long)g.mcux * g.mcuy * g.nb;
     c->g = g;
     c->nimg = 1;
-    c->stage = ST_NONE; c->have_planes = false; c->down_done = false;
+    c->stage = ST_NONE; c->have_planes = false; c->down_done = false; c->coef_valid = false;
     return JPG_OK;
 }
 
@@ -257,12 +260,14 @@ static int regrow(jpg_ctx *c, T *&p, size_t n) {
     return grow(c, p, cap, n);
 }
 
-// back-end buffers of the slot being written, for c->nimg images of the current geometry
-static int ensure_entropy(jpg_ctx *c) {
+// back-end buffers of the slot being written, for c->nimg images of the current geometry;
+// coded: the chunks are the tiles of the fused coding kernel instead of runs of 64 blocks
+static int ensure_entropy(jpg_ctx *c, bool coded) {
     jpg_ctx::Slot &sl = S(c);
     const size_t nimg = (size_t)(c->nimg > 0 ? c->nimg : 1);
     const size_t nblk = (size_t)c->g.nblocks;
-    const size_t nchunks = (nblk + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
+    const size_t nchunks = coded ? (size_t)coded_tiles(c->g) : (nblk + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
+    const size_t slot_words = coded ? (size_t)coded_slot_words(c->g) : (size_t)CHUNK_STRIDE_WORDS;
     if ((nchunks + 63) / 64 > (size_t)MAX_GROUPS) return JPG_ERR_CAPACITY;
     const size_t cstride = (nchunks + 63) / 64 * 64;
     const size_t bits_bytes = worst_bits_bytes(nblk);
@@ -271,9 +276,10 @@ static int ensure_entropy(jpg_ctx *c) {
     sl.eb.nimg = (int)nimg;
     sl.eb.nchunks = (long long)nchunks;
     sl.eb.cstride = (long long)cstride;
+    sl.eb.slot_words = (int)slot_words;
     int e;
     if ((e = grow(c, sl.eb.clen, sl.cap_clen, nimg * cstride))) return e;
-    if ((e = grow(c, sl.eb.sparse, sl.cap_sparse, nimg * cstride * CHUNK_STRIDE_WORDS))) return e;
+    if ((e = grow(c, sl.eb.sparse, sl.cap_sparse, nimg * cstride * slot_words))) return e;
     if ((e = grow(c, sl.eb.scan, sl.cap_scan, nimg * scan_stride))) return e;
     sl.eb.scan_stride = scan_stride;
     if (nimg > sl.cap_status) {
@@ -431,6 +437,7 @@ extern "C" int jpg_dct_quant(jpg_ctx *c) {
     const bool sub = c->h != 1 || c->v != 1;
     HIP_TRY(c, launch_dct_planes(c->g, c->algo, c->d_plane[0], sub ? c->d_down[0] : c->d_plane[1],
                                  sub ? c->d_down[1] : c->d_plane[2], c->d_coef, c->stream));
+    c->coef_valid = true;
     c->stage = ST_COEF;
     return JPG_OK;
 }
@@ -448,11 +455,12 @@ static int harvest_timing(jpg_ctx *c) {
     return JPG_OK;
 }
 
-// the fused front kernel (for one image, or for the batch srcs[0..n-1]), with its start and end
-// time stamps taken when timing is on
-static int queue_front(jpg_ctx *c, const uint8_t *const *srcs = nullptr, int n = 1) {
+// Launch a kernel that takes a pair of events for its own start and end time stamps (both null when
+// this launch is not timed): launch(e0, e1) -> hipError_t.  n = images of the launch.
+template <class F>
+static int launch_timed(jpg_ctx *c, int n, F launch) {
     if (!c->timing || (c->t_seen++ % (uint64_t)c->timing) != 0) {
-        HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream, nullptr, nullptr, srcs, n));
+        HIP_TRY(c, launch(nullptr, nullptr));
         return JPG_OK;
     }
     if (c->t_pending == jpg_ctx::TIMING_RING) {
@@ -463,9 +471,20 @@ static int queue_front(jpg_ctx *c, const uint8_t *const *srcs = nullptr, int n =
     if (!e0) HIP_TRY(c, hipEventCreate(&e0));
     if (!e1) HIP_TRY(c, hipEventCreate(&e1));
     // the events take the dispatch's own time stamps: no extra packets in the stream
-    HIP_TRY(c, launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream, e0, e1, srcs, n));
+    HIP_TRY(c, launch(e0, e1));
     c->t_imgs[c->t_pending] = n;
     c->t_pending++;
+    return JPG_OK;
+}
+
+// the fused front kernel (for one image, or for the batch srcs[0..n-1])
+static int queue_front(jpg_ctx *c, const uint8_t *const *srcs = nullptr, int n = 1) {
+    if (int e = ensure_coef(c)) return e;
+    if (int e = launch_timed(c, n, [&](hipEvent_t e0, hipEvent_t e1) {
+            return launch_front(c->g, c->algo, c->d_src, c->d_coef, c->stream, e0, e1, srcs, n);
+        }))
+        return e;
+    c->coef_valid = true;
     return JPG_OK;
 }
 
@@ -493,10 +512,10 @@ extern "C" int jpg_front_time(jpg_ctx *c, double *total_ms, uint64_t *launches, 
     return JPG_OK;
 }
 
-// Queue the entropy kernel on `stream` into the slot c->cur.  The slot's previous stuffing kernel
+// Get the slot c->cur ready for a coding kernel on `stream`.  The slot's previous stuffing kernel
 // (possibly on stream_b) must have finished with the chunks first.
-static int queue_entropy(jpg_ctx *c, const int16_t pred[3]) {
-    if (int e = ensure_entropy(c)) return e;
+static int prepare_slot(jpg_ctx *c, bool coded) {
+    if (int e = ensure_entropy(c, coded)) return e;
     jpg_ctx::Slot &sl = S(c);
     if (sl.busy) HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.s_done, 0));
     // errors are tagged with a launch number; clear the word before the number repeats
@@ -508,8 +527,14 @@ static int queue_entropy(jpg_ctx *c, const int16_t pred[3]) {
     sl.eb.host_status = sl.h_status;
     sl.dense_valid = false;
     c->view = c->cur;
-    static const int16_t zero[3] = {0, 0, 0};   // src/jpeg/entropy_coding.rs:38-40
-    HIP_TRY(c, launch_entropy(c->g, c->d_coef, pred ? pred : zero, sl.eb, c->stream));
+    return JPG_OK;
+}
+
+static const int16_t ZERO_PRED[3] = {0, 0, 0};   // src/jpeg/entropy_coding.rs:38-40
+
+static int queue_entropy(jpg_ctx *c, const int16_t pred[3]) {
+    if (int e = prepare_slot(c, false)) return e;
+    HIP_TRY(c, launch_entropy(c->g, c->d_coef, pred ? pred : ZERO_PRED, S(c).eb, c->stream));
     return JPG_OK;
 }
 
@@ -557,10 +582,19 @@ static int make_dense(jpg_ctx *c) {
     return JPG_OK;
 }
 
+// The fused coding kernel leaves no coefficients behind.  When they are asked for afterwards they are
+// computed from the context's own copy of the rows; rows the caller owns may be gone by then.
+static int need_coef(jpg_ctx *c) {
+    if (c->coef_valid) return JPG_OK;
+    if (c->nimg != 1 || !c->d_src || c->d_src != c->d_src_own) return JPG_ERR_STATE;
+    return queue_front(c);
+}
+
 static int entropy_common(jpg_ctx *c, const int16_t *pred, uint64_t *nbits) {
     if (!c) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_COEF) return JPG_ERR_STATE;
     if (int e = use_device(c)) return e;
+    if (int e = need_coef(c)) return e;
     c->npend = 0;
     if (int e = queue_entropy(c, pred)) return e;
     if (int e = make_dense(c)) return e;
@@ -604,6 +638,7 @@ extern "C" int jpg_last_dc(jpg_ctx *c, int16_t dc[3]) {
     if (!c || !dc) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_COEF) return JPG_ERR_STATE;
     if (int e = use_device(c)) return e;
+    if (int e = need_coef(c)) return e;
     HIP_TRY(c, launch_last_dc(c->g, c->d_coef, c->d_dc, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_dc, c->d_dc, 3 * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -634,7 +669,6 @@ extern "C" int jpg_front_device(jpg_ctx *c, const uint8_t *dev_pixels, int32_t W
     if (int e = use_device(c)) return e;
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
     if (int e = stage_input(c, dev_pixels, false)) return e;
-    if (int e = ensure_coef(c)) return e;
     if (int e = queue_front(c)) return e;
     c->stage = ST_COEF;
     return JPG_OK;
@@ -646,16 +680,28 @@ extern "C" int jpg_front_host(jpg_ctx *c, const uint8_t *pixels, int32_t W, int3
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
     if (int e = stage_input(c, pixels, true)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // caller may reuse `pixels`
-    if (int e = ensure_coef(c)) return e;
     if (int e = queue_front(c)) return e;
     c->stage = ST_COEF;
     return JPG_OK;
 }
 
-// entropy coding on `stream`, stuffing on stream_b, into the slot the previous fused encode did not use
-static int queue_back_end(jpg_ctx *c) {
+// A whole encode of the staged rows (or of the batch srcs[0..n-1]): coding on `stream`, stuffing on
+// stream_b, into the slot the previous encodes do not use.  The fused coding kernel where the
+// geometry allows it, else the front kernel and the entropy kernel.
+static int queue_encode(jpg_ctx *c, const uint8_t *const *srcs = nullptr, int n = 1) {
     c->cur = (c->cur + 1) % jpg_ctx::NSLOT;
-    if (int e = queue_entropy(c, nullptr)) return e;
+    if (!c->two_kernels && coded_supported(c->g)) {
+        if (int e = prepare_slot(c, true)) return e;
+        if (int e = launch_timed(c, n, [&](hipEvent_t e0, hipEvent_t e1) {
+                return launch_coded(c->g, c->algo, c->d_src, srcs, n, ZERO_PRED, S(c).eb, c->stream, e0, e1);
+            }))
+            return e;
+        c->coef_valid = false;
+    } else {
+        if (int e = queue_front(c, srcs, n)) return e;
+        if (int e = queue_entropy(c, nullptr)) return e;
+    }
+    c->stage = ST_COEF;
     if (int e = queue_stuff(c, 0, 0, 1, c->stream_b)) return e;
     if (c->npend == jpg_ctx::NSLOT) {   // the oldest queued result is overwritten unread, as documented
         for (int k = 1; k < c->npend; k++) c->fifo[k - 1] = c->fifo[k];
@@ -667,8 +713,11 @@ static int queue_back_end(jpg_ctx *c) {
 
 extern "C" int jpg_encode_device_async(jpg_ctx *c, const uint8_t *dev_pixels, int32_t W, int32_t H, uint32_t stride,
                                        int bottom_up) {
-    if (int e = jpg_front_device(c, dev_pixels, W, H, stride, bottom_up)) return e;
-    return queue_back_end(c);
+    if (!c || !dev_pixels) return JPG_ERR_BAD_ARG;
+    if (int e = use_device(c)) return e;
+    if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
+    if (int e = stage_input(c, dev_pixels, false)) return e;
+    return queue_encode(c);
 }
 
 // ---- batches of equally sized images: one launch of each kernel for all of them ----
@@ -687,13 +736,10 @@ extern "C" int jpg_encode_batch_device_async(jpg_ctx *c, const uint8_t *const *d
         if (!dev_pixels[i] || (reinterpret_cast<uintptr_t>(dev_pixels[i]) & 3)) return JPG_ERR_BAD_ARG;
     c->nimg = n;
     c->d_src = dev_pixels[0];
-    jpg_ctx::Slot &next = c->slot[(c->cur + 1) % jpg_ctx::NSLOT];   // the slot queue_back_end is about to use
+    jpg_ctx::Slot &next = c->slot[(c->cur + 1) % jpg_ctx::NSLOT];   // the slot queue_encode is about to use
     if (int e = grow(c, next.d_srcs, next.cap_srcs, (size_t)n)) return e;
     HIP_TRY(c, hipMemcpyAsync(next.d_srcs, dev_pixels, (size_t)n * sizeof(uint8_t *), hipMemcpyHostToDevice, c->stream));
-    if (int e = ensure_coef(c)) return e;
-    if (int e = queue_front(c, next.d_srcs, n)) return e;
-    c->stage = ST_COEF;
-    return queue_back_end(c);
+    return queue_encode(c, next.d_srcs, n);
 }
 
 extern "C" int jpg_batch_result(jpg_ctx *c, int32_t i, uint64_t *nbits, size_t *stuffed_len, const uint8_t **scan_dev) {
@@ -778,10 +824,7 @@ extern "C" int jpg_encode_scan(jpg_ctx *c, const uint8_t *pixels, int32_t W, int
     if (int e = use_device(c)) return e;
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
     if (int e = stage_input(c, pixels, true)) return e;
-    if (int e = ensure_coef(c)) return e;
-    if (int e = queue_front(c)) return e;
-    c->stage = ST_COEF;
-    if (int e = queue_back_end(c)) return e;
+    if (int e = queue_encode(c)) return e;
     if (int e = jpg_finish(c, nullptr, nullptr)) return e;
     const jpg_ctx::Slot &sl = V(c);
     void *host = nullptr;
@@ -876,6 +919,7 @@ extern "C" int jpg_get_coeffs(jpg_ctx *c, int comp, int16_t *out, size_t cap) {
     const size_t n = comp ? (size_t)c->g.Wc * c->g.Hc : (size_t)c->g.Wp * c->g.Hp;
     if (cap < n * sizeof(int16_t)) return JPG_ERR_CAPACITY;
     if (int e = use_device(c)) return e;
+    if (int e = need_coef(c)) return e;
     if (int e = grow(c, c->d_tmp16, c->tmp16_cap, n)) return e;
     HIP_TRY(c, launch_unscan(c->g, c->d_coef, comp, c->d_tmp16, c->stream));
     HIP_TRY(c, hipMemcpyAsync(out, c->d_tmp16, n * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
@@ -888,3 +932,6 @@ extern "C" uint64_t jpg_front_bytes(const jpg_ctx *c) {
     return (uint64_t)c->g.stride * c->g.H + 2ull * 64ull * (uint64_t)c->g.nblocks;
 }
 extern "C" uint64_t jpg_num_blocks(const jpg_ctx *c) { return c ? (uint64_t)c->g.nblocks : 0; }
+extern "C" int jpg_fused_coding(const jpg_ctx *c) {
+    return c && c->g.W > 0 && !c->two_kernels && coded_supported(c->g) ? 1 : 0;
+}

@@ -1,0 +1,218 @@
+// Fused encoder: BMP rows -> YCbCr -> chroma box average -> 8x8 DCT ->
+// quantisation -> zigzag -> Huffman coding, one kernel; neither planes nor
+// coefficients are ever written to memory.  Replaces, for whole encodes, the
+// loop of JpegImage::from_bmp (src/jpeg/jpeg_image.rs:121-134),
+// chrominance_downsampling (src/jpeg/sampling.rs:46-102), dct_and_quantization
+// (src/jpeg/dct_quant.rs:15-61) and generate_entropy_encoded_data
+// (src/jpeg/entropy_coding.rs:16-125) of the reference.
+//
+// One workgroup owns a tile of 512 pixels x one MCU row, converts and transforms
+// it (tile.hpp) and then codes the tile's blocks, which are consecutive in the
+// scan: one thread per block measures its block, a scan over the workgroup
+// places it, and the bits are assembled in LDS and stored to the tile's own
+// fixed-size slot together with the tile's length.  The stream kernels of
+// entropy.hip concatenate the slots.
+//
+// The only value a tile needs from outside is the DC of the last block of each
+// component before it (the three predictor chains of
+// src/jpeg/entropy_coding.rs:38-40,149-150).  Instead of waiting for the tile
+// before it, the workgroup converts and transforms that one MCU again (the
+// otherwise idle fourth wave does it), so that no workgroup depends on another.
+#include <hip/hip_ext.h>
+
+#include "coding.hpp"
+#include "tile.hpp"
+
+namespace jpg {
+
+constexpr int WIN_WORDS = 2048;   // LDS words a tile's bits are assembled in per pass (a tile rarely needs two)
+
+struct CodedArgs {
+    const uint8_t *src;
+    const uint8_t *const *srcs;   // a batch: pixel array of each image (else null)
+    Geom g;
+    int16_t pred[3];              // DC predictors the first MCU of every image starts from
+    uint32_t epoch;               // tags errors (see raise_error)
+    long long cstride;            // tile slots per image in clen / sparse
+    int slot_words;               // words per tile slot
+    uint32_t *clen;               // [nimg][cstride] out: bits of each tile
+    uint32_t *sparse;             // [nimg][cstride][slot_words] out: the tile's bits, MSB first in each word
+    DevStatus *status;            // [nimg]
+};
+
+template <int HS, int VS, int ALGO>
+__global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
+    using C = TileCfg<HS, VS>;
+    constexpr int HV = HS * VS;
+    static_assert(C::BLOCKS % 64 == 0 && C::BLOCKS <= THREADS, "one thread per block");
+    // Y, Cb, Cr planes of the tile and of the MCU before it; then the finished blocks of both
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(C::BLOCKS + 3) * OUT_STRIDE];
+    __shared__ uint32_t sLut[LUT_WORDS];
+    __shared__ uint32_t sWin[WIN_WORDS + 2];
+    __shared__ uint32_t sTot[THREADS / 64], sPass[THREADS / 64];
+    uint8_t *sY = lds;
+    uint8_t *sCb = lds + C::TILE_H * TILE_W;
+    uint8_t *sCr = sCb + 8 * C::CW;
+    uint8_t *hY = lds + C::PLANE_BYTES;
+    const Geom &g = a.g;
+
+    const int tiles_x = (g.mcux + C::MCUS - 1) / C::MCUS;
+    int tile = blockIdx.x;
+    int img = 0;
+    const uint8_t *src = a.src;
+    if (a.srcs) {
+        const int per_image = tiles_x * g.mcuy;
+        img = tile / per_image;
+        tile -= img * per_image;
+        src = a.srcs[img];
+    }
+    const int tile_x = tile % tiles_x;
+    const int tile_y = tile / tiles_x;
+    const int mcu0 = tile_x * C::MCUS;                        // first MCU column of the tile
+    const int mcus = min(C::MCUS, g.mcux - mcu0);             // MCUs really present
+    const int x0 = mcu0 * 8 * HS;
+    const int y0 = tile_y * C::TILE_H;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // the MCU before the tile in the scan: the last one of the row above for the first tile of a row
+    const bool has_halo = tile > 0;
+    const int hmx = mcu0 ? mcu0 - 1 : g.mcux - 1, hmy = mcu0 ? tile_y : tile_y - 1;
+
+    for (int i = tid; i < LUT_WORDS; i += THREADS) sLut[i] = (&HUFF_DEV.e[0][0])[i];
+    for (int i = tid; i < WIN_WORDS + 2; i += THREADS) sWin[i] = 0;
+
+    tile_convert<HS, VS>(src, g, x0, y0, mcus, sY, sCb, sCr, tid);
+    if (has_halo)
+        halo_convert<HS, VS>(src, g, hmx * 8 * HS, hmy * 8 * VS, hY, hY + C::HALO_Y, hY + C::HALO_Y + 64,
+                             tid - 64 * C::HALO_WAVE);
+    __syncthreads();
+    tile_transform<HS, VS, ALGO, true>(lds, mcus, tid, has_halo);
+    __syncthreads();
+
+    // ---------------- coding: thread `tid` codes block `tid` of the tile ----------------
+    const int nblk = mcus * C::NBLK;
+    const bool valid = tid < nblk;
+    DevStatus *status = a.status + img;
+    const uint16_t *slot = reinterpret_cast<const uint16_t *>(&lds[(valid ? tid : 0) * OUT_STRIDE]);
+    uint32_t mlo = 0, mhi = 0, len = 0;
+    int dc_diff = 0;
+    const uint32_t *lut = sLut;
+    AccWriter acc;                                            // blocks of up to ACC_BITS bits are kept whole
+    if (valid) {
+        uint4 q[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) q[i] = reinterpret_cast<const uint4 *>(slot)[i];
+        nonzero_mask(q, mlo, mhi);
+        mlo &= ~1u;                                           // the DC symbol is coded separately
+        // DC difference against the previous block of the same component
+        const int jb = tid % C::NBLK;
+        const int comp = jb < HV ? 0 : jb - HV + 1;
+        const int back = prev_distance(jb, C::NBLK, HV);
+        int pdc;
+        if (tid >= back) pdc = (int16_t) * reinterpret_cast<const uint16_t *>(&lds[(tid - back) * OUT_STRIDE]);
+        else if (has_halo) pdc = (int16_t) * reinterpret_cast<const uint16_t *>(&lds[(C::BLOCKS + comp) * OUT_STRIDE]);
+        else pdc = comp == 0 ? a.pred[0] : (comp == 1 ? a.pred[1] : a.pred[2]);
+        dc_diff = (int16_t)((int)(int16_t)(q[0].x & 0xffff) - pdc);
+        lut = sLut + (comp ? jpgtab::HUFF_LUT_STRIDE : 0);
+        len = code_block(slot, mlo, mhi, dc_diff, lut, status, a.epoch, acc);
+    }
+    const uint32_t sc = wave_incl_scan(len);
+    if (lane == 63) sTot[wave] = sc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; w++) {
+        const uint32_t t = sTot[w];
+        if (w < wave) before += t;
+        total += t;
+    }
+    const uint32_t end = before + sc;                         // bits of the tile up to and including this block
+    const size_t slot_index = (size_t)img * (size_t)a.cstride + (size_t)tile;
+    if (tid == 0) a.clen[slot_index] = total;
+
+    // A tile too long for the LDS window goes in several passes, each starting in the word the
+    // previous one ended in (that word is carried over and stored again).
+    uint32_t *dst = a.sparse + slot_index * (size_t)a.slot_words;
+    constexpr uint32_t WINDOW = WIN_WORDS * 32;               // bits per pass
+    uint32_t done = 0;                                        // bits of the tile already stored
+    for (;;) {
+        const uint32_t start = done & 31;
+        // blocks that end within the window (at least one: a block is shorter than WINDOW - 31 bits)
+        const bool mine = valid && end > done && end - done + start <= WINDOW;
+        uint32_t pass_bits;
+        if (total - done + start <= WINDOW) {
+            pass_bits = total - done;
+        } else {
+            const uint32_t cand = __shfl(mine ? end - done : 0u, 63 - __clzll(__ballot(mine) | 1ull));
+            if (lane == 0) sPass[wave] = cand;
+            __syncthreads();
+            pass_bits = 0;
+#pragma unroll
+            for (int w = 0; w < THREADS / 64; w++) pass_bits = max(pass_bits, sPass[w]);
+        }
+        const uint32_t nwords = (start + pass_bits + 31) >> 5;
+        if (mine) {
+            const uint32_t pos = end - len - done + start;
+            if (len <= ACC_BITS) {
+                acc.emit(sWin, pos, len);
+            } else {                                          // long block: walk it again
+                BitWriter w;
+                w.init(sWin, pos);
+                code_block(slot, mlo, mhi, dc_diff, lut, status, a.epoch, w);
+            }
+        }
+        __syncthreads();
+        const uint32_t endb = start + pass_bits;
+        const uint32_t carry = (endb & 31) ? sWin[endb >> 5] : 0u;
+        for (uint32_t i = tid; i < nwords; i += THREADS) dst[(done >> 5) + i] = sWin[i];
+        done += pass_bits;
+        if (done >= total) break;
+        __syncthreads();
+        for (uint32_t i = tid; i < nwords + 1; i += THREADS) sWin[i] = i ? 0u : carry;
+        __syncthreads();
+    }
+}
+
+template <int HS, int VS>
+static hipError_t launch_coded_hv(const CodedArgs &a, int algo, int nimg, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    using C = TileCfg<HS, VS>;
+    const int tiles_x = (a.g.mcux + C::MCUS - 1) / C::MCUS;
+    const long long tiles = (long long)tiles_x * a.g.mcuy;
+    if (tiles <= 0 || tiles * nimg > 0x7fffffffLL || tiles > a.cstride || a.slot_words != coded_slot_words(a.g))
+        return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(tiles * nimg)), block(THREADS);
+    switch (algo) {
+        case ALGO_REAL: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, a); break;
+        case ALGO_BIN: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, a); break;
+        case ALGO_REAL_STRICT: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_REAL_STRICT>), grid, block, 0, s, e0, e1, 0, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+static int tile_mcus(const Geom &g) { return TILE_W / (8 * g.h); }
+
+bool coded_supported(const Geom &g) {
+    // Every row of tiles must begin with a full tile: the stream kernels tabulate a bounded number of
+    // slots per segment of the stream, which holds when no two consecutive slots are both nearly empty.
+    return g.mcux >= tile_mcus(g);
+}
+
+long long coded_tiles(const Geom &g) { return (long long)((g.mcux + tile_mcus(g) - 1) / tile_mcus(g)) * g.mcuy; }
+
+int coded_slot_words(const Geom &g) { return tile_mcus(g) * g.nb * SLOT_WORDS_PER_BLOCK; }
+
+hipError_t launch_coded(const Geom &g, int algo, const uint8_t *src, const uint8_t *const *srcs, int nimg,
+                        const int16_t pred[3], const EntropyBufs &b, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    // rows are read as dwords (the caller checks the pointers of a batch)
+    if ((!srcs && (reinterpret_cast<uintptr_t>(src) & 3)) || (g.stride & 3) || nimg < 1 || !coded_supported(g))
+        return hipErrorInvalidValue;
+    if (!srcs) nimg = 1;
+    if (nimg != (b.nimg > 0 ? b.nimg : 1) || b.nchunks != coded_tiles(g)) return hipErrorInvalidValue;
+    CodedArgs a{src, srcs, g, {pred[0], pred[1], pred[2]}, b.epoch, b.cstride, b.slot_words, b.clen, b.sparse, b.status};
+    if (g.h == 2 && g.v == 2) return launch_coded_hv<2, 2>(a, algo, nimg, s, e0, e1);
+    if (g.h == 2 && g.v == 1) return launch_coded_hv<2, 1>(a, algo, nimg, s, e0, e1);
+    if (g.h == 1 && g.v == 1) return launch_coded_hv<1, 1>(a, algo, nimg, s, e0, e1);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace jpg

@@ -20,14 +20,10 @@
 // their place, straight from the chunk slots.  Stuffing then inserts 0x00 after
 // every 0xFF; the output offset of a segment comes from three levels of running
 // sums of the 0xFF counts, published by the segments before it.
-#include "../../include/jpeg_hip.h"
-#include "internal.hpp"
-#include "tables.h"
+#include "coding.hpp"
 
 namespace jpg {
 
-__device__ const jpgtab::HuffLut HUFF_DEV{};
-constexpr int LUT_WORDS = 2 * jpgtab::HUFF_LUT_STRIDE;
 #ifndef JPG_ENT_THREADS
 #define JPG_ENT_THREADS 256
 #endif
@@ -39,17 +35,6 @@ constexpr int SLOT_BYTES = 144;                 // 128-byte block + 16: conflict
 #define JPG_ENT_OUT_WORDS 64
 #endif
 constexpr int OUT_WORDS = JPG_ENT_OUT_WORDS;    // LDS words of a chunk's bits coded per pass
-
-// inclusive prefix sum across the 64 lanes of a wavefront (DPP row shifts and broadcasts)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
-    return v;
-}
 
 struct EntArgs {
     const int16_t *coef;
@@ -64,12 +49,6 @@ struct EntArgs {
     DevStatus *status;       // [nimg]
 };
 
-// Errors are recorded as -(epoch << 8 | code) with atomicMin, so a newer launch always
-// overrides an older one and the word never needs clearing between launches.
-__device__ __forceinline__ void raise_error(DevStatus *st, uint32_t epoch, int status_code) {
-    atomicMin(&st->error, -(int)((epoch << 8) | (uint32_t)(-status_code)));
-}
-
 // hand-off word: {epoch:14 | valid:1 | value:49}
 __device__ __forceinline__ uint64_t hw_pack(uint32_t epoch, uint64_t value) {
     return ((uint64_t)((epoch << 1) | 1u) << 49) | value;
@@ -81,137 +60,6 @@ __device__ __forceinline__ void hw_store(uint64_t *p, uint64_t w) {
 }
 __device__ __forceinline__ uint64_t hw_load(const uint64_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// MSB-first bit writer into a zeroed LDS word array (words may be shared with
-// neighbouring blocks, hence OR)
-struct BitWriter {
-    uint32_t *out;
-    uint32_t wpos;
-    uint64_t acc;   // the low `n` bits are pending
-    uint32_t n;
-    __device__ __forceinline__ void init(uint32_t *o, uint32_t bitpos) {
-        out = o; wpos = bitpos >> 5; n = bitpos & 31; acc = 0;
-    }
-    // len <= 32, value < 2^len, n < 32 on entry
-    __device__ __forceinline__ void put(uint32_t value, uint32_t len) {
-        acc = (acc << len) | value;
-        n += len;
-        if (n >= 32) {
-            n -= 32;
-            atomicOr(&out[wpos++], (uint32_t)(acc >> n));
-        }
-    }
-    __device__ __forceinline__ void finish() {
-        if (n) atomicOr(&out[wpos], (uint32_t)(acc << (32 - n)));
-    }
-};
-
-// Collects the last 128 bits put; a block of at most 128 bits is then complete in registers.
-struct AccWriter {
-    uint64_t hi = 0, lo = 0;
-    // 2 <= len <= 26
-    __device__ __forceinline__ void put(uint32_t value, uint32_t len) {
-        hi = (hi << len) | (lo >> (64 - len));
-        lo = (lo << len) | value;
-    }
-    __device__ __forceinline__ void finish() {}
-    // ORs the n collected bits (1 <= n <= 128) into `out` starting at bit `pos`
-    __device__ __forceinline__ void emit(uint32_t *out, uint32_t pos, uint32_t n) const {
-        uint64_t H, L;
-        if (n <= 64) {
-            H = lo << (64 - n);
-            L = 0;
-        } else {
-            const uint32_t s = 128 - n;                          // 0..63
-            H = (hi << s) | (s ? lo >> (64 - s) : 0);
-            L = lo << s;
-        }
-        const uint32_t w0 = (uint32_t)(H >> 32), w1 = (uint32_t)H, w2 = (uint32_t)(L >> 32), w3 = (uint32_t)L;
-        const uint32_t sh = pos & 31;
-        uint32_t *o = out + (pos >> 5);
-        const uint32_t x0 = w0 >> sh, x1 = __funnelshift_r(w1, w0, sh), x2 = __funnelshift_r(w2, w1, sh),
-                       x3 = __funnelshift_r(w3, w2, sh), x4 = __funnelshift_r(0u, w3, sh);
-        atomicOr(&o[0], x0);
-        if (x1) atomicOr(&o[1], x1);
-        if (x2) atomicOr(&o[2], x2);
-        if (x3) atomicOr(&o[3], x3);
-        if (x4) atomicOr(&o[4], x4);
-    }
-};
-constexpr uint32_t ACC_BITS = 128;
-
-// Codes one block held in LDS at `slot` (64 int16, zigzag order).  mask: bit k
-// set where coefficient k is non-zero (k >= 1).  Returns the coded length.
-template <class W>
-__device__ __forceinline__ uint32_t code_block(const uint16_t *slot, uint32_t mlo, uint32_t mhi, int dc_diff,
-                                               const uint32_t *lut, DevStatus *st, uint32_t epoch, W &w) {
-    // DC: size = bit length of |diff| (src/jpeg/entropy_coding.rs:127-134,149-160)
-    uint32_t mag = (uint32_t)(dc_diff < 0 ? -dc_diff : dc_diff);
-    uint32_t size = 32 - __clz(mag);
-    if (size > 11) {
-        raise_error(st, epoch, JPG_ERR_DC_RANGE);
-        size = 0;
-    }
-    // negative values: v + (1 << size) - 1 (src/jpeg/entropy_coding.rs:140-142)
-    uint32_t amp = (uint32_t)(dc_diff < 0 ? dc_diff - 1 : dc_diff) & ((1u << size) - 1u);
-    uint32_t t = lut[256 + size];
-    uint32_t bits = (t >> 16) + size;
-    w.put(((t & 0xffff) << size) | amp, (t >> 16) + size);
-    const uint32_t zrl = lut[0xf0];
-    int prevk = 0;
-    uint64_t m = ((uint64_t)mhi << 32) | mlo;
-    // the coefficient of the next symbol is read while the current one is coded
-    int k = m ? __ffsll((unsigned long long)m) - 1 : 0;
-    int v = (int16_t)slot[k];
-    while (m) {
-        m &= m - 1;
-        const int kn = m ? __ffsll((unsigned long long)m) - 1 : 0;
-        const int vn = (int16_t)slot[kn];
-        uint32_t run = (uint32_t)(k - prevk - 1);
-        prevk = k;
-        while (run >= 16) {                                      // ZRL per 16 zeros (src/jpeg/entropy_coding.rs:179-185)
-            w.put(zrl & 0xffff, zrl >> 16);
-            bits += zrl >> 16;
-            run -= 16;
-        }
-        mag = (uint32_t)(v < 0 ? -v : v);
-        size = 32 - __clz(mag);
-        if (size > 10) {
-            raise_error(st, epoch, JPG_ERR_AC_RANGE);
-            size = 0;
-        }
-        amp = (uint32_t)(v < 0 ? v - 1 : v) & ((1u << size) - 1u);
-        t = lut[(run << 4) | size];
-        bits += (t >> 16) + size;
-        w.put(((t & 0xffff) << size) | amp, (t >> 16) + size);
-        k = kn;
-        v = vn;
-    }
-    if (prevk != 63) {                                           // trailing zeros -> EOB (src/jpeg/entropy_coding.rs:171-177)
-        t = lut[0x00];
-        bits += t >> 16;
-        w.put(t & 0xffff, t >> 16);
-    }
-    w.finish();
-    return bits;
-}
-
-// bit k set where the k-th int16 of the block (8 uint4) is non-zero
-__device__ __forceinline__ void nonzero_mask(const uint4 (&q)[8], uint32_t &mlo, uint32_t &mhi) {
-    uint32_t m[2] = {0, 0};
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t w[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = 8 * i + 2 * j;
-            const uint32_t lo = (w[j] & 0xffffu) ? 1u : 0u, hi = (w[j] >> 16) ? 1u : 0u;
-            m[k >> 5] |= (lo << (k & 31)) | (hi << ((k + 1) & 31));
-        }
-    }
-    mlo = m[0];
-    mhi = m[1];
 }
 
 // Three levels of running sums over items 0..n-1 (chunks of blocks here, segments
@@ -283,12 +131,6 @@ __device__ __forceinline__ uint64_t sums_prefix(const Sums &s, long long i, uint
     for (long long j0 = 0; j0 < h; j0 += 64)
         sh += hw_wait(&s.hyp[j0 + lane], j0 + lane < h, j0 ? 0 : pr.wh, s.epoch, timeout);
     return wave_sum64(sh) + sum_g + sum_a;
-}
-
-// block `jb` of its MCU (0..nb-1): the block before it in the same component's DC chain,
-// relative to the block itself (src/jpeg/entropy_coding.rs:74-124)
-__device__ __forceinline__ int prev_distance(int jb, int nb, int hv) {
-    return jb >= hv ? nb : (jb > 0 ? 1 : nb - hv + 1);
 }
 
 __device__ __forceinline__ uint32_t mod_small(uint32_t x, uint32_t nb, uint32_t magic) {   // x < 1024
@@ -463,6 +305,7 @@ struct StreamArgs {
     // a batch: image i is handled by workgroups i * wpi .. (i + 1) * wpi - 1 and owns a stride of each array
     int wpi;
     long long cstride;       // chunk slots per image in sparse / clen
+    size_t slot_words;       // words per chunk slot
     size_t out_stride;       // bytes per image in `out`
     size_t agg_stride, grp_stride, hyp_stride;   // words per image in agg / grp / hyp
     DevStatus *status;       // [nimg] nbits, scan_bytes and tail out
@@ -538,7 +381,7 @@ template <bool STUFF>
 __global__ __launch_bounds__(ST_THREADS) void k_stream(StreamArgs a) {
     {   // this workgroup's image: from here on `a` describes that image alone
         const int img = blockIdx.x / a.wpi;
-        a.sparse += (size_t)img * a.cstride * CHUNK_STRIDE_WORDS;
+        a.sparse += (size_t)img * a.cstride * a.slot_words;
         a.clen += img * a.cstride;
         a.out += img * a.out_stride;
         a.agg += img * a.agg_stride;
@@ -644,7 +487,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_stream(StreamArgs a) {
         JPG_STAMP(2);
 
         // ---- gather: every word of a chunk slot that overlaps the segment is OR-ed into place
-        const uint32_t *slots = a.sparse + (size_t)cbase * CHUNK_STRIDE_WORDS;
+        const uint32_t *slots = a.sparse + (size_t)cbase * a.slot_words;
         {
             int n = 0;
             if (tid < TABLE) {
@@ -682,7 +525,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_stream(StreamArgs a) {
                 if (m < rounds && f < nwant) {
                     while (sW[i + 1] <= f) i++;
                     const int j = sW0[i] + (f - sW[i]);
-                    wv[m] = slots[(size_t)i * CHUNK_STRIDE_WORDS + j];
+                    wv[m] = slots[(size_t)i * a.slot_words + j];
                     pos[m] = sT[i] + 32 * j;                      // where the word's first bit goes (>= -31)
                 }
                 f++;
@@ -808,7 +651,7 @@ hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred
                           hipStream_t s) {
     const long long nchunks = (g.nblocks + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
     const int nimg = b.nimg > 0 ? b.nimg : 1;
-    if (nchunks != b.nchunks || b.cstride < nchunks || (nimg > 1 && g.nblocks >= (1LL << 31))) return hipErrorInvalidValue;
+    if (nchunks != b.nchunks || b.cstride < nchunks || b.slot_words != CHUNK_STRIDE_WORDS || (nimg > 1 && g.nblocks >= (1LL << 31))) return hipErrorInvalidValue;
     // as many workgroups as fit on the device at once (each loops over its share of the chunks)
     static long long resident_cache[64] = {};
     int dev = 0;
@@ -836,7 +679,7 @@ static hipError_t launch_stream(const EntropyBufs &b, uint64_t bit_offset, uint8
                                 size_t out_stride, hipStream_t s) {
     const int nimg = b.nimg > 0 ? b.nimg : 1;
     const int ngroups = (int)((b.nchunks + 63) / 64);
-    if (ngroups > MAX_GROUPS || !out) return hipErrorInvalidValue;
+    if (ngroups > MAX_GROUPS || !out || b.slot_words <= 0) return hipErrorInvalidValue;
     const size_t lds = (ngroups + 1) * sizeof(uint64_t);
     // no more workgroups than fit on the device at once: a segment waits for the segments before it, which
     // must therefore be running or finished whatever the dispatch order
@@ -861,7 +704,7 @@ static hipError_t launch_stream(const EntropyBufs &b, uint64_t bit_offset, uint8
     if ((size_t)nimg > cap) return hipErrorInvalidValue;       // the caller splits larger batches
     size_t wpi = cap / nimg;                                     // workgroups per image
     if (wpi > b.nseg_cap) wpi = b.nseg_cap ? b.nseg_cap : 1;
-    StreamArgs a{b.sparse, b.clen, b.nchunks, ngroups, (int)wpi, b.cstride, out_stride, b.nseg_cap, b.nseg_cap / 64 + 1,
+    StreamArgs a{b.sparse, b.clen, b.nchunks, ngroups, (int)wpi, b.cstride, (size_t)b.slot_words, out_stride, b.nseg_cap, b.nseg_cap / 64 + 1,
                  b.nseg_cap / 4096 + 1, b.status, (uint32_t)(bit_offset & 7), head_bits, is_last, b.sagg, b.sgrp, b.shyp,
                  b.stuff_epoch, b.epoch, out, b.host_status, b.trace};
     hipLaunchKernelGGL(k_stream<STUFF>, dim3((unsigned)(wpi * nimg)), dim3(ST_THREADS), lds, s, a);

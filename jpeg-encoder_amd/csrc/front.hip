@@ -5,82 +5,16 @@
 // (src/jpeg/sampling.rs:46-102) and dct_and_quantization
 // (src/jpeg/dct_quant.rs:15-61) of the reference.
 //
-// One workgroup owns a tile of 512 pixels x one MCU row (8*v image rows):
-//   phase A  every thread converts groups of 4 pixels x v rows read straight
-//            from global memory (12 contiguous bytes per row and lane, so a
-//            wave reads 768 contiguous bytes) and leaves Y and the averaged
-//            Cb/Cr as bytes in LDS;
-//   phase B  one thread per 8x8 block (wave-uniform component class, so the
-//            quantisation table is a compile-time constant) transforms it in
-//            registers and parks the 128-byte zigzag block in LDS;
-//   phase C  the tile's blocks, contiguous in the scan layout, go to global
-//            memory as coalesced 16-byte stores.
+// One workgroup owns a tile of 512 pixels x one MCU row (8*v image rows): it
+// converts and transforms the tile (tile.hpp); the tile's blocks, contiguous in
+// the scan layout, then go to global memory as coalesced 16-byte stores.
 // HBM traffic is the algorithmic minimum: every input byte is read once, every
 // coefficient written once.
 #include <hip/hip_ext.h>
 
-#include "internal.hpp"
-#include "transform.hpp"
+#include "tile.hpp"
 
 namespace jpg {
-
-constexpr int TILE_W = 512;     // pixels per tile row
-constexpr int OUT_STRIDE = 144; // bytes between parked blocks in LDS (128 + 16: conflict-free b128 access)
-constexpr int THREADS = 256;
-
-template <int HS, int VS>
-struct TileCfg {
-    static constexpr int MCUS = TILE_W / (8 * HS);           // MCUs per tile
-    static constexpr int NBLK = HS * VS + 2;                  // blocks per MCU
-    static constexpr int TILE_H = 8 * VS;                     // image rows per tile
-    static constexpr int YWAVES = VS;                         // 64 luma blocks per block row
-    static constexpr int CWAVES = (2 * MCUS) / 64;            // chroma blocks: MCUS per component
-    static constexpr int CW = TILE_W / HS;                    // chroma samples per tile row
-    static constexpr int BLOCKS = MCUS * NBLK;
-    static constexpr int ITEMS = (TILE_W / 4) * 8;            // groups of 4 pixels x VS rows
-    static constexpr int ROUNDS = ITEMS / THREADS;            // items per thread in a full tile
-    static constexpr int PLANE_BYTES = TILE_H * TILE_W + 2 * 8 * CW;
-    static constexpr int OUT_BYTES = BLOCKS * OUT_STRIDE;
-    static constexpr int LDS_BYTES = PLANE_BYTES > OUT_BYTES ? PLANE_BYTES : OUT_BYTES;
-    static_assert(YWAVES + CWAVES <= THREADS / 64, "one thread per block");
-    static_assert(ITEMS % THREADS == 0, "whole rounds");
-};
-
-// 4 pixels of one row: 12 bytes B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3 -> packed Y, Cb, Cr bytes
-__device__ __forceinline__ void convert4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t &y4, uint32_t (&cb)[4],
-                                         uint32_t (&cr)[4]) {
-    float fy[4], fb[4], fr[4];
-    rgb_to_ycbcr_f((float)((d0 >> 16) & 0xff), (float)((d0 >> 8) & 0xff), (float)(d0 & 0xff), fy[0], fb[0], fr[0]);
-    rgb_to_ycbcr_f((float)((d1 >> 8) & 0xff), (float)(d1 & 0xff), (float)(d0 >> 24), fy[1], fb[1], fr[1]);
-    rgb_to_ycbcr_f((float)(d2 & 0xff), (float)(d1 >> 24), (float)((d1 >> 16) & 0xff), fy[2], fb[2], fr[2]);
-    rgb_to_ycbcr_f((float)(d2 >> 24), (float)((d2 >> 16) & 0xff), (float)((d2 >> 8) & 0xff), fy[3], fb[3], fr[3]);
-    // `as u8` (truncation; nothing saturates): the four Y bytes are converted into place
-    cvt_pack8<0>(y4, fy[0]);
-    cvt_pack8<1>(y4, fy[1]);
-    cvt_pack8<2>(y4, fy[2]);
-    cvt_pack8<3>(y4, fy[3]);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        cb[q] = (uint32_t)fb[q];
-        cr[q] = (uint32_t)fr[q];
-    }
-}
-
-template <int HS, int VS>
-__device__ __forceinline__ void store_chroma(uint8_t *sCb, uint8_t *sCr, int iy, int ix, const uint32_t (&cbs)[4],
-                                             const uint32_t (&crs)[4]) {
-    using C = TileCfg<HS, VS>;
-    // box average, floor(sum / (h*v)) (src/jpeg/sampling.rs:66-73)
-    if constexpr (HS == 2) {
-        const uint32_t b0 = (cbs[0] + cbs[1]) / (2 * VS), b1 = (cbs[2] + cbs[3]) / (2 * VS);
-        const uint32_t r0 = (crs[0] + crs[1]) / (2 * VS), r1 = (crs[2] + crs[3]) / (2 * VS);
-        *reinterpret_cast<uint16_t *>(&sCb[iy * C::CW + 2 * ix]) = (uint16_t)(b0 | (b1 << 8));
-        *reinterpret_cast<uint16_t *>(&sCr[iy * C::CW + 2 * ix]) = (uint16_t)(r0 | (r1 << 8));
-    } else {
-        *reinterpret_cast<uint32_t *>(&sCb[iy * C::CW + 4 * ix]) = cbs[0] | (cbs[1] << 8) | (cbs[2] << 16) | (cbs[3] << 24);
-        *reinterpret_cast<uint32_t *>(&sCr[iy * C::CW + 4 * ix]) = crs[0] | (crs[1] << 8) | (crs[2] << 16) | (crs[3] << 24);
-    }
-}
 
 // A batch of equally sized images is one launch: srcs[i] (when given) is the pixel array of image
 // i, whose tiles follow those of image i-1 in the grid and whose blocks follow in `coef`.
@@ -111,104 +45,9 @@ __global__ __launch_bounds__(THREADS) void k_front(const uint8_t *__restrict__ s
     const int y0 = tile_y * C::TILE_H;
     const int tid = threadIdx.x;
 
-    // ---------------- phase A: colour conversion + chroma average ----------
-    if (mcus == C::MCUS && x0 + TILE_W <= g.W && y0 + C::TILE_H <= g.H) {
-        // interior tile: every thread owns ROUNDS items; all loads are issued before the arithmetic
-        uint32_t d[C::ROUNDS][VS][3];
-        const int ix = tid & 127;
-#pragma unroll
-        for (int k = 0; k < C::ROUNDS; k++) {
-            const int iy = 2 * k + (tid >> 7);
-#pragma unroll
-            for (int r = 0; r < VS; r++) {
-                const int y = y0 + iy * VS + r;
-                const size_t row = (size_t)(g.bottom_up ? g.H - 1 - y : y) * g.stride;
-                const uint32_t *p = reinterpret_cast<const uint32_t *>(src + row + (size_t)3 * (x0 + 4 * ix));
-                d[k][r][0] = p[0]; d[k][r][1] = p[1]; d[k][r][2] = p[2];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < C::ROUNDS; k++) {
-            const int iy = 2 * k + (tid >> 7);
-            uint32_t cbs[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int r = 0; r < VS; r++) {
-                uint32_t y4, cb[4], cr[4];
-                convert4(d[k][r][0], d[k][r][1], d[k][r][2], y4, cb, cr);
-                *reinterpret_cast<uint32_t *>(&sY[(iy * VS + r) * TILE_W + 4 * ix]) = y4;
-#pragma unroll
-                for (int q = 0; q < 4; q++) { cbs[q] += cb[q]; crs[q] += cr[q]; }
-            }
-            store_chroma<HS, VS>(sCb, sCr, iy, ix, cbs, crs);
-        }
-    } else {
-        // edge tile: samples outside W x H stay 0 in all three planes
-        // (zero-filled planes of src/jpeg/jpeg_image.rs:59-70)
-        const int items_x = mcus * 2 * HS;
-        for (int it = tid; it < items_x * 8; it += THREADS) {
-            const int ix = it % items_x, iy = it / items_x;
-            const int x = x0 + 4 * ix;
-            uint32_t cbs[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int r = 0; r < VS; r++) {
-                const int ly = iy * VS + r, y = y0 + ly;
-                uint32_t yy[4] = {0, 0, 0, 0};
-                if (y < g.H) {
-                    const uint8_t *p = src + (size_t)(g.bottom_up ? g.H - 1 - y : y) * g.stride;
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        if (x + q < g.W) {
-                            const uint8_t *c = p + (size_t)3 * (x + q);
-                            uint32_t cb, cr;
-                            rgb_to_ycbcr((float)c[2], (float)c[1], (float)c[0], yy[q], cb, cr);
-                            cbs[q] += cb;
-                            crs[q] += cr;
-                        }
-                }
-                *reinterpret_cast<uint32_t *>(&sY[ly * TILE_W + 4 * ix]) = yy[0] | (yy[1] << 8) | (yy[2] << 16) | (yy[3] << 24);
-            }
-            store_chroma<HS, VS>(sCb, sCr, iy, ix, cbs, crs);
-        }
-    }
+    tile_convert<HS, VS>(src, g, x0, y0, mcus, sY, sCb, sCr, tid);
     __syncthreads();
-
-    // ---------------- phase B: one thread per 8x8 block ---------------------
-    const int wave = tid >> 6, lane = tid & 63;
-    uint32_t px[16];
-    int bi = -1;                                               // block index inside the tile, scan order
-    if (wave < C::YWAVES) {
-        // luma: block row `wave`, block column `lane` of the tile
-        const int m = lane / HS;                               // MCU inside the tile
-        if (m < mcus) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(&sY[(wave * 8 + r) * TILE_W + lane * 8]);
-                px[2 * r] = v.x;
-                px[2 * r + 1] = v.y;
-            }
-            bi = m * C::NBLK + wave * HS + (lane % HS);
-        }
-    } else if (wave < C::YWAVES + C::CWAVES) {
-        const int ci = (wave - C::YWAVES) * 64 + lane;         // 0 .. 2*MCUS-1
-        const int comp = ci / C::MCUS;                         // 0 Cb, 1 Cr
-        const int m = ci % C::MCUS;
-        if (m < mcus) {
-            const uint8_t *pl = comp ? sCr : sCb;
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(&pl[r * C::CW + m * 8]);
-                px[2 * r] = v.x;
-                px[2 * r + 1] = v.y;
-            }
-            bi = m * C::NBLK + HS * VS + comp;
-        }
-    }
-    __syncthreads();   // every sample is in registers: the planes' space becomes the output staging area
-    if (bi >= 0) {
-        uint32_t *slot = reinterpret_cast<uint32_t *>(&lds[bi * OUT_STRIDE]);
-        if (wave < C::YWAVES) transform_block<ALGO, false>(px, slot);
-        else transform_block<ALGO, true>(px, slot);
-    }
+    tile_transform<HS, VS, ALGO, false>(lds, mcus, tid, false);
     __syncthreads();
 
     // ---------------- phase C: coalesced copy-out ---------------------------

@@ -34,9 +34,11 @@ enum { ALGO_REAL = 0, ALGO_BIN = 1, ALGO_REAL_STRICT = 2 };
 constexpr int CHUNK_BLOCKS = 64;
 // worst-case coded size of one block: DC 9+11 bits, 63 AC x (16+10) bits
 constexpr int MAX_BLOCK_BITS = 20 + 63 * 26;
-// words of a chunk's slot in the sparse buffer: room for 64 blocks of maximum size
-constexpr int CHUNK_STRIDE_WORDS = 3328;
-static_assert(CHUNK_STRIDE_WORDS * 32 >= CHUNK_BLOCKS * MAX_BLOCK_BITS + 64, "chunk slot too small");
+// words a block gets in a slot of the sparse buffer: room for a block of maximum size
+constexpr int SLOT_WORDS_PER_BLOCK = 52;
+// words of a chunk's slot in the sparse buffer
+constexpr int CHUNK_STRIDE_WORDS = CHUNK_BLOCKS * SLOT_WORDS_PER_BLOCK;
+static_assert(SLOT_WORDS_PER_BLOCK * 32 >= MAX_BLOCK_BITS + 1, "chunk slot too small");
 // byte-stuffing works on segments of this many unstuffed bytes
 constexpr int STUFF_SEG = 4096;
 // groups of 64 chunks a stream reader can tabulate in LDS (52 KiB of LDS; limits an image to 27M blocks)
@@ -50,12 +52,15 @@ struct DevStatus {
     uint32_t tail;        // bits of the dropped partial byte (stripes)
 };
 
+// A "chunk" is the unit whose bits one kernel assembles on its own: 64 consecutive blocks
+// (k_entropy) or the blocks of one tile of the fused encoder (k_coded).
 struct EntropyBufs {
     int nimg;              // images of the current launch (a batch of equally sized images), >= 1
     long long nchunks;     // chunks of one image
     long long cstride;     // chunk slots per image in clen / sparse (nchunks rounded up to 64)
+    int slot_words;        // words per chunk slot (blocks per chunk x SLOT_WORDS_PER_BLOCK)
     uint32_t *clen;        // [nimg][cstride] bits of each chunk
-    uint32_t *sparse;      // [nimg][cstride][CHUNK_STRIDE_WORDS] coded bits of each chunk, MSB first in each word
+    uint32_t *sparse;      // [nimg][cstride][slot_words] coded bits of each chunk, MSB first in each word
     uint32_t epoch;        // tags the error word of the current entropy launch (host side, 1..2^22)
     DevStatus *status;       // [nimg]
     DevStatus *host_status;  // [nimg] pinned host copy the last kernel fills (may be null)
@@ -91,6 +96,14 @@ hipError_t launch_last_dc(const Geom &g, const int16_t *coef, int16_t *dc3, hipS
 // pred: the 3 DC predictors (Y, Cb, Cr) the first blocks start from
 hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred[3], const EntropyBufs &b,
                           hipStream_t s);
+// The fused encoder: pixels to coded tiles (chunks = tiles; b describes coded_tiles(g) slots of
+// coded_slot_words(g) words).  Only for geometries coded_supported() accepts.
+bool coded_supported(const Geom &g);
+long long coded_tiles(const Geom &g);
+int coded_slot_words(const Geom &g);
+hipError_t launch_coded(const Geom &g, int algo, const uint8_t *src, const uint8_t *const *srcs, int nimg,
+                        const int16_t pred[3], const EntropyBufs &b, hipStream_t s, hipEvent_t e0 = nullptr,
+                        hipEvent_t e1 = nullptr);
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s);
 // writes the dense stream to b.bits
 hipError_t launch_dense(const EntropyBufs &b, hipStream_t s);

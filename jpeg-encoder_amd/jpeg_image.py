@@ -226,6 +226,10 @@ class Encoder:
     def num_blocks(self):
         return self._L.jpg_num_blocks(self._ctx)
 
+    def fused_coding(self):
+        """True when whole encodes of the current image size run the single pixels-to-bits kernel."""
+        return bool(self._L.jpg_fused_coding(self._ctx))
+
 
 class JpegImage:
     """Same five steps, same names, as the reference's JpegImage."""
