@@ -16,8 +16,9 @@
 // The only value a tile needs from outside is the DC of the last block of each
 // component before it (the three predictor chains of
 // src/jpeg/entropy_coding.rs:38-40,149-150).  Instead of waiting for the tile
-// before it, the workgroup converts and transforms that one MCU again (the
-// otherwise idle fourth wave does it), so that no workgroup depends on another.
+// before it, the workgroup converts that one MCU again and computes the three DC
+// coefficients (the fourth wave does it while the other three transform the
+// tile's blocks), so that no workgroup depends on another.
 #include <hip/hip_ext.h>
 
 #include "coding.hpp"
@@ -25,7 +26,10 @@
 
 namespace jpg {
 
-constexpr int WIN_WORDS = 2048;   // LDS words a tile's bits are assembled in per pass (a tile rarely needs two)
+#ifndef JPG_WIN_WORDS
+#define JPG_WIN_WORDS 2048
+#endif
+constexpr int WIN_WORDS = JPG_WIN_WORDS;   // LDS words a tile's bits are assembled in per pass
 
 struct CodedArgs {
     const uint8_t *src;
@@ -45,15 +49,16 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
     using C = TileCfg<HS, VS>;
     constexpr int HV = HS * VS;
     static_assert(C::BLOCKS % 64 == 0 && C::BLOCKS <= THREADS, "one thread per block");
-    // Y, Cb, Cr planes of the tile and of the MCU before it; then the finished blocks of both
-    __shared__ __attribute__((aligned(16))) uint8_t lds[(C::BLOCKS + 3) * OUT_STRIDE];
+    // Y, Cb, Cr planes of the tile; then its finished blocks
+    __shared__ __attribute__((aligned(16))) uint8_t lds[C::LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t sHalo[C::HALO_BYTES];   // planes of the MCU before the tile
+    __shared__ int16_t sHaloDc[4];                                          // its last Y, Cb, Cr DC coefficients
     __shared__ uint32_t sLut[LUT_WORDS];
     __shared__ uint32_t sWin[WIN_WORDS + 2];
     __shared__ uint32_t sTot[THREADS / 64], sPass[THREADS / 64];
     uint8_t *sY = lds;
     uint8_t *sCb = lds + C::TILE_H * TILE_W;
     uint8_t *sCr = sCb + 8 * C::CW;
-    uint8_t *hY = lds + C::PLANE_BYTES;
     const Geom &g = a.g;
 
     const int tiles_x = (g.mcux + C::MCUS - 1) / C::MCUS;
@@ -74,18 +79,26 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
     const int y0 = tile_y * C::TILE_H;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // the MCU before the tile in the scan: the last one of the row above for the first tile of a row
+#ifdef JPG_ABL_NOHALO
+    const bool has_halo = false;
+#else
     const bool has_halo = tile > 0;
+#endif
     const int hmx = mcu0 ? mcu0 - 1 : g.mcux - 1, hmy = mcu0 ? tile_y : tile_y - 1;
 
     for (int i = tid; i < LUT_WORDS; i += THREADS) sLut[i] = (&HUFF_DEV.e[0][0])[i];
     for (int i = tid; i < WIN_WORDS + 2; i += THREADS) sWin[i] = 0;
 
+    HaloRegs<VS> halo;
+    halo_load<HS, VS>(src, g, hmx * 8 * HS, hmy * 8 * VS, has_halo ? tid - 64 * C::SPARE_WAVE : -1, halo);
     tile_convert<HS, VS>(src, g, x0, y0, mcus, sY, sCb, sCr, tid);
-    if (has_halo)
-        halo_convert<HS, VS>(src, g, hmx * 8 * HS, hmy * 8 * VS, hY, hY + C::HALO_Y, hY + C::HALO_Y + 64,
-                             tid - 64 * C::HALO_WAVE);
     __syncthreads();
-    tile_transform<HS, VS, ALGO, true>(lds, mcus, tid, has_halo);
+    tile_transform<HS, VS, ALGO>(lds, mcus, tid, [&] {
+        if (!has_halo) return;
+        halo_convert<HS, VS>(src, g, hmx * 8 * HS, hmy * 8 * VS, sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, halo);
+        __builtin_amdgcn_wave_barrier();   // (the LDS accesses of one wave execute in order)
+        halo_dc<HS, VS, ALGO>(sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, sHaloDc);
+    });
     __syncthreads();
 
     // ---------------- coding: thread `tid` codes block `tid` of the tile ----------------
@@ -101,7 +114,11 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
         uint4 q[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) q[i] = reinterpret_cast<const uint4 *>(slot)[i];
+#ifndef JPG_ABL_NOMASK
         nonzero_mask(q, mlo, mhi);
+#else
+        mlo = q[1].x; mhi = q[7].y;
+#endif
         mlo &= ~1u;                                           // the DC symbol is coded separately
         // DC difference against the previous block of the same component
         const int jb = tid % C::NBLK;
@@ -109,11 +126,17 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
         const int back = prev_distance(jb, C::NBLK, HV);
         int pdc;
         if (tid >= back) pdc = (int16_t) * reinterpret_cast<const uint16_t *>(&lds[(tid - back) * OUT_STRIDE]);
-        else if (has_halo) pdc = (int16_t) * reinterpret_cast<const uint16_t *>(&lds[(C::BLOCKS + comp) * OUT_STRIDE]);
+        else if (has_halo) pdc = sHaloDc[comp];
         else pdc = comp == 0 ? a.pred[0] : (comp == 1 ? a.pred[1] : a.pred[2]);
         dc_diff = (int16_t)((int)(int16_t)(q[0].x & 0xffff) - pdc);
         lut = sLut + (comp ? jpgtab::HUFF_LUT_STRIDE : 0);
+#ifdef JPG_ABL_NOCODE
+        len = 17; acc.put(0x1555, 17);
+#elif defined(JPG_ABL_NOAC)
+        len = code_block(slot, 0, 0, dc_diff, lut, status, a.epoch, acc);
+#else
         len = code_block(slot, mlo, mhi, dc_diff, lut, status, a.epoch, acc);
+#endif
     }
     const uint32_t sc = wave_incl_scan(len);
     if (lane == 63) sTot[wave] = sc;

@@ -143,18 +143,38 @@ __device__ __forceinline__ uint32_t code_block(const uint16_t *slot, uint32_t ml
     return bits;
 }
 
-// bit k set where the k-th int16 of the block (8 uint4) is non-zero
+// bit 0 set when the low half of w is non-zero, bit 16 when the high half is: min(half, 1) on both
+// halves at once (written out because the compiler turns the vector min into compares and selects)
+__device__ __forceinline__ uint32_t halves_nonzero(uint32_t w) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w), "s"(0x00010001u));
+    return r;
+}
+
+// the low 16 bits of x moved to the even bit positions
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+// bit k set where the k-th int16 of the block (8 uint4) is non-zero: per 16 dwords the flags of
+// the low halves are collected in bits 0..15 and those of the high halves in bits 16..31, then the
+// two are interleaved
 __device__ __forceinline__ void nonzero_mask(const uint4 (&q)[8], uint32_t &mlo, uint32_t &mhi) {
-    uint32_t m[2] = {0, 0};
+    uint32_t m[2];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t w[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+    for (int h = 0; h < 2; h++) {
+        uint32_t f = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int k = 8 * i + 2 * j;
-            const uint32_t lo = (w[j] & 0xffffu) ? 1u : 0u, hi = (w[j] >> 16) ? 1u : 0u;
-            m[k >> 5] |= (lo << (k & 31)) | (hi << ((k + 1) & 31));
+        for (int i = 0; i < 4; i++) {
+            const uint32_t w[4] = {q[4 * h + i].x, q[4 * h + i].y, q[4 * h + i].z, q[4 * h + i].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) f |= halves_nonzero(w[j]) << (4 * i + j);
         }
+        m[h] = spread16(f & 0xffffu) | (spread16(f >> 16) << 1);
     }
     mlo = m[0];
     mhi = m[1];

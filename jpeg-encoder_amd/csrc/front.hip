@@ -47,7 +47,7 @@ __global__ __launch_bounds__(THREADS) void k_front(const uint8_t *__restrict__ s
 
     tile_convert<HS, VS>(src, g, x0, y0, mcus, sY, sCb, sCr, tid);
     __syncthreads();
-    tile_transform<HS, VS, ALGO, false>(lds, mcus, tid, false);
+    tile_transform<HS, VS, ALGO>(lds, mcus, tid, [] {});
     __syncthreads();
 
     // ---------------- phase C: coalesced copy-out ---------------------------

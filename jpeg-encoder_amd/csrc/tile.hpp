@@ -34,12 +34,11 @@ struct TileCfg {
     static constexpr int PLANE_BYTES = TILE_H * TILE_W + 2 * 8 * CW;
     static constexpr int OUT_BYTES = BLOCKS * OUT_STRIDE;
     static constexpr int LDS_BYTES = PLANE_BYTES > OUT_BYTES ? PLANE_BYTES : OUT_BYTES;
-    // the MCU before the tile (k_coded only): its planes live behind the tile's, its blocks behind the tile's
+    // the planes of one more MCU (k_coded: the MCU before the tile)
     static constexpr int HALO_Y = 64 * HS * VS;               // bytes of its luma samples
     static constexpr int HALO_BYTES = HALO_Y + 2 * 64;
-    static constexpr int HALO_WAVE = THREADS / 64 - 1;        // the wave with no block of the tile to transform
-    static_assert(YWAVES + CWAVES <= HALO_WAVE, "one thread per block, one wave to spare");
-    static_assert(PLANE_BYTES + HALO_BYTES <= OUT_BYTES, "halo planes share the staging area");
+    static constexpr int SPARE_WAVE = THREADS / 64 - 1;       // the wave with no block of the tile to transform
+    static_assert(YWAVES + CWAVES <= SPARE_WAVE, "one thread per block, one wave to spare");
     static_assert(ITEMS % THREADS == 0, "whole rounds");
 };
 
@@ -155,41 +154,78 @@ __device__ __forceinline__ void tile_convert(const uint8_t *__restrict__ src, co
     }
 }
 
-// The MCU at pixel (hx0, hy0), converted by the first 2*HS*8 threads of the spare wave into
-// hY (8*HS bytes per row), hCb, hCr (8 bytes per row).
+// The MCU at pixel (hx0, hy0), converted by the first 2*HS*8 threads of the spare wave (t = index
+// in that wave) into hY (8*HS bytes per row), hCb, hCr (8 bytes per row).  In two steps, so that the
+// loads can be issued before the tile's own and be used after them.
+template <int VS>
+struct HaloRegs {
+    uint32_t d[VS][3];
+    bool full;            // the item lies inside the image: its rows were loaded as dwords
+};
+
 template <int HS, int VS>
-__device__ __forceinline__ void halo_convert(const uint8_t *__restrict__ src, const Geom &g, int hx0, int hy0, uint8_t *hY,
-                                             uint8_t *hCb, uint8_t *hCr, int t) {
-    if (t < 0 || t >= 2 * HS * 8) return;
+__device__ __forceinline__ void halo_load(const uint8_t *__restrict__ src, const Geom &g, int hx0, int hy0, int t,
+                                          HaloRegs<VS> &h) {
     const int ix = t % (2 * HS), iy = t / (2 * HS);
     const int x = hx0 + 4 * ix, ytop = hy0 + iy * VS;
-    uint32_t yw[VS], cbs[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
-    if (x + 4 <= g.W && ytop + VS <= g.H) {
+    h.full = t >= 0 && t < 2 * HS * 8 && x + 4 <= g.W && ytop + VS <= g.H;
 #pragma unroll
-        for (int r = 0; r < VS; r++) {
+    for (int r = 0; r < VS; r++) {
+        h.d[r][0] = h.d[r][1] = h.d[r][2] = 0;
+        if (h.full) {
             const int y = ytop + r;
             const size_t row = (size_t)(g.bottom_up ? g.H - 1 - y : y) * g.stride;
             const uint32_t *p = reinterpret_cast<const uint32_t *>(src + row + (size_t)3 * x);
+            h.d[r][0] = p[0]; h.d[r][1] = p[1]; h.d[r][2] = p[2];
+        }
+    }
+}
+
+template <int HS, int VS>
+__device__ __forceinline__ void halo_convert(const uint8_t *__restrict__ src, const Geom &g, int hx0, int hy0, uint8_t *hY,
+                                             uint8_t *hCb, uint8_t *hCr, int t, const HaloRegs<VS> &h) {
+    if (t < 0 || t >= 2 * HS * 8) return;
+    const int ix = t % (2 * HS), iy = t / (2 * HS);
+    uint32_t yw[VS], cbs[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
+    if (h.full) {
+#pragma unroll
+        for (int r = 0; r < VS; r++) {
             uint32_t cb[4], cr[4];
-            convert4(p[0], p[1], p[2], yw[r], cb, cr);
+            convert4(h.d[r][0], h.d[r][1], h.d[r][2], yw[r], cb, cr);
 #pragma unroll
             for (int q = 0; q < 4; q++) { cbs[q] += cb[q]; crs[q] += cr[q]; }
         }
     } else {
-        convert_item_edge<VS>(src, g, x, ytop, yw, cbs, crs);
+        convert_item_edge<VS>(src, g, hx0 + 4 * ix, hy0 + iy * VS, yw, cbs, crs);
     }
 #pragma unroll
     for (int r = 0; r < VS; r++) *reinterpret_cast<uint32_t *>(&hY[(iy * VS + r) * 8 * HS + 4 * ix]) = yw[r];
     store_chroma<HS, VS, 8>(hCb, hCr, iy, ix, cbs, crs);
 }
 
+// The DC coefficients of the last luma block and of the chroma blocks of the MCU whose planes
+// halo_convert left in hY / hCb / hCr, computed by lanes 0..2 of the calling wave into dc[0..2].
+template <int HS, int VS, int ALGO>
+__device__ __forceinline__ void halo_dc(const uint8_t *hY, const uint8_t *hCb, const uint8_t *hCr, int lane, int16_t *dc) {
+    if (lane >= 3) return;
+    const uint8_t *pl = lane == 0 ? hY + (8 * (VS - 1)) * 8 * HS + 8 * (HS - 1) : (lane == 1 ? hCb : hCr);
+    const int pitch = lane == 0 ? 8 * HS : 8;
+    uint32_t px[16];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(&pl[r * pitch]);
+        px[2 * r] = v.x;
+        px[2 * r + 1] = v.y;
+    }
+    dc[lane] = (int16_t)(lane ? transform_dc<ALGO, true>(px) : transform_dc<ALGO, false>(px));
+}
+
 // One thread per block: samples from the planes at the start of `lds` into registers, then (the
 // planes' space being reused) the finished blocks to lds[bi * OUT_STRIDE], bi = position of the block
-// in the scan order of the tile.  HALO: three lanes of the spare wave also transform the last luma
-// block and the chroma blocks of the MCU converted by halo_convert into slots BLOCKS, BLOCKS + 1,
-// BLOCKS + 2.  Contains one barrier; the caller places one after it.
-template <int HS, int VS, int ALGO, bool HALO>
-__device__ __forceinline__ void tile_transform(uint8_t *lds, int mcus, int tid, bool has_halo) {
+// in the scan order of the tile.  The last wave has no block to transform: it runs spare() meanwhile.
+// Contains one barrier; the caller places one after it.
+template <int HS, int VS, int ALGO, class Spare>
+__device__ __forceinline__ void tile_transform(uint8_t *lds, int mcus, int tid, Spare spare) {
     using C = TileCfg<HS, VS>;
     const uint8_t *sY = lds;
     const uint8_t *sCb = lds + C::TILE_H * TILE_W;
@@ -197,7 +233,6 @@ __device__ __forceinline__ void tile_transform(uint8_t *lds, int mcus, int tid, 
     const int wave = tid >> 6, lane = tid & 63;
     uint32_t px[16];
     int bi = -1;                                               // block index inside the tile, scan order
-    bool chroma = wave >= C::YWAVES;
     if (wave < C::YWAVES) {
         // luma: block row `wave`, block column `lane` of the tile
         const int m = lane / HS;                               // MCU inside the tile
@@ -224,26 +259,14 @@ __device__ __forceinline__ void tile_transform(uint8_t *lds, int mcus, int tid, 
             }
             bi = m * C::NBLK + HS * VS + comp;
         }
-    } else if (HALO && wave == C::HALO_WAVE && lane < 3 && has_halo) {
-        const uint8_t *hY = lds + C::PLANE_BYTES;
-        // lane 0: the MCU's last luma block; lanes 1, 2: its Cb and Cr blocks
-        const uint8_t *pl = lane == 0 ? hY + (8 * (VS - 1)) * 8 * HS + 8 * (HS - 1) : hY + C::HALO_Y + (lane - 1) * 64;
-        const int pitch = lane == 0 ? 8 * HS : 8;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint2 v = *reinterpret_cast<const uint2 *>(&pl[r * pitch]);
-            px[2 * r] = v.x;
-            px[2 * r + 1] = v.y;
-        }
-        bi = C::BLOCKS + lane;
-        chroma = lane != 0;
     }
     __syncthreads();   // every sample is in registers: the planes' space becomes the output staging area
     if (bi >= 0) {
         uint32_t *slot = reinterpret_cast<uint32_t *>(&lds[bi * OUT_STRIDE]);
-        if (!chroma) transform_block<ALGO, false>(px, slot);
+        if (wave < C::YWAVES) transform_block<ALGO, false>(px, slot);
         else transform_block<ALGO, true>(px, slot);
     }
+    if (wave == C::SPARE_WAVE) spare();
 }
 
 }  // namespace jpg

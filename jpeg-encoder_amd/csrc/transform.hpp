@@ -313,6 +313,64 @@ __device__ __forceinline__ void transform_bin(const uint32_t (&px)[16], uint32_t
     store_zigzag(res, slot);
 }
 
+// --- the DC coefficient alone ------------------------------------------------
+// The same operations on the same values as the full transforms above, with everything that does
+// not reach coefficient 0 left out, so the result is the one the full transform stores at slot[0].
+template <bool CHROMA>
+__device__ __forceinline__ int dc_real(const uint32_t (&px)[16]) {
+    float t0[8];
+#pragma unroll
+    for (int x = 0; x < 8; x++) {
+        float e[8], o[8];
+#pragma unroll
+        for (int y = 0; y < 8; y++) e[y] = (float)((px[2 * x + (y >> 2)] >> (8 * (y & 3))) & 0xffu);
+        dct8(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], o);
+        t0[x] = o[0];
+    }
+    float o[8];
+    dct8_quant<CHROMA, 0>(t0[0], t0[1], t0[2], t0[3], t0[4], t0[5], t0[6], t0[7], o);
+    const float s = dct_scale(0, 0) * (o[0] - 8192.0f);
+    return (int)div_const(s, (float)quant<CHROMA>(0), rcp_rn(quant<CHROMA>(0)));
+}
+
+template <bool CHROMA>
+__device__ __forceinline__ int dc_real_strict(const uint32_t (&px)[16]) {
+    const float inv_sqrt2 = 1.0f / 1.41421356237309505f;
+    float sum = 0.0f;
+#pragma unroll
+    for (int x = 0; x < 8; x++)
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+            const float t = sample(px, x, y) * cosv(0, x);
+            const float p = t * cosv(0, y);
+            sum = sum + p;
+        }
+    const float su = 0.25f * inv_sqrt2;
+    return quantise_real(sum, su * inv_sqrt2, (float)quant<CHROMA>(0));
+}
+
+template <bool CHROMA>
+__device__ __forceinline__ int dc_bin(const uint32_t (&px)[16]) {
+    int a[64];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) a[r * 8 + c] = sample_i(px, r, c);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        bin8(a[i * 8 + 0], a[i * 8 + 1], a[i * 8 + 2], a[i * 8 + 3], a[i * 8 + 4], a[i * 8 + 5], a[i * 8 + 6],
+             a[i * 8 + 7]);
+    bin8(a[0], a[8], a[16], a[24], a[32], a[40], a[48], a[56]);
+    return a[0] / quant<CHROMA>(0);
+}
+
+template <int ALGO, bool CHROMA>
+__device__ __forceinline__ int transform_dc(const uint32_t (&px)[16]) {
+    if constexpr (ALGO == 0) return dc_real<CHROMA>(px);
+    else if constexpr (ALGO == 1) return dc_bin<CHROMA>(px);
+    else return dc_real_strict<CHROMA>(px);
+}
+
 template <int ALGO, bool CHROMA>
 __device__ __forceinline__ void transform_block(const uint32_t (&px)[16], uint32_t *slot) {
     if constexpr (ALGO == 0) transform_real<CHROMA>(px, slot);

@@ -6,7 +6,7 @@ name=$1; shift
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/variants; mkdir -p $O/obj_$name
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fhip-fp32-correctly-rounded-divide-sqrt -I$R/include -I$R/jpeg-encoder_amd/csrc"
-for f in front staged entropy api; do
+for f in front coded staged entropy api; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $R/jpeg-encoder_amd/csrc/$f.hip -o $O/obj_$name/$f.o &
 done
 wait
