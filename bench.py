@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--ratio", default="4:2:0")
     ap.add_argument("--dct-algorithm", default="real-dct")
-    ap.add_argument("--batch", type=int, default=16, help="images per rank per step")
+    ap.add_argument("--batch", type=int, default=64, help="images per rank per step")
     ap.add_argument("--distinct", type=int, default=4,
                     help="images synthesised from scratch; the others are shifted copies of them at other addresses")
     ap.add_argument("--isolated", action="store_true",
@@ -46,9 +46,10 @@ def parse():
                          "2 overlaps the tail of one encode with the front kernel of the next (higher MP/s, but "
                          "the kernels then share the device and their individual durations grow)")
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2, 3], help="encodes in flight per context")
-    ap.add_argument("--per-launch", type=int, default=0,
+    ap.add_argument("--per-launch", type=int, default=32,
                     help="images per launch set (jpg_encode_batch_device_async); 0 = the whole batch of the step, "
-                         "1 = one launch set per image")
+                         "1 = one launch set per image.  With several sets per step the stuffing kernel of one set "
+                         "runs under the coding kernel of the next")
     ap.add_argument("--time-every", type=int, default=16,
                     help="take the start/end time stamps of every n-th front-kernel launch of the timed region "
                          "(roofline figure); a stamped launch costs some host time, hence the sampling")
@@ -233,8 +234,10 @@ def main():
         if fused:
             # for comparison, outside the timed region: the front kernel alone (coefficients to memory,
             # as the staged calls and the stripes use it), single-image launches
+            for k in range(4):
+                enc.front_device(imgs[k % len(imgs)].data_ptr(), W, H, stride, True)
             enc.set_timing(1)
-            for k in range(8):
+            for k in range(12):
                 enc.front_device(imgs[k % len(imgs)].data_ptr(), W, H, stride, True)
             ms, n, im = enc.front_time()
             enc.set_timing(0)

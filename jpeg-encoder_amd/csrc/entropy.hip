@@ -378,7 +378,8 @@ static_assert(SEG_WORDS == WPT * ST_THREADS && ST_THREADS >= TABLE, "whole words
 // The kernel is a chain of short dependent steps; 16 waves per workgroup keep the per-thread
 // instruction count of every step small (a lone wave issues an instruction only every ~5 ns).
 template <bool STUFF>
-__global__ __launch_bounds__(ST_THREADS) void k_stream(StreamArgs a) {
+// (8 waves per SIMD = 4 workgroups per CU: the more segments are in flight, the shorter the chain per workgroup)
+__global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_stream(StreamArgs a) {
     {   // this workgroup's image: from here on `a` describes that image alone
         const int img = blockIdx.x / a.wpi;
         a.sparse += (size_t)img * a.cstride * a.slot_words;
@@ -682,22 +683,24 @@ static hipError_t launch_stream(const EntropyBufs &b, uint64_t bit_offset, uint8
     if (ngroups > MAX_GROUPS || !out || b.slot_words <= 0) return hipErrorInvalidValue;
     const size_t lds = (ngroups + 1) * sizeof(uint64_t);
     // no more workgroups than fit on the device at once: a segment waits for the segments before it, which
-    // must therefore be running or finished whatever the dispatch order
-    static long long resident_cache[2][64] = {};
+    // must therefore be running or finished whatever the dispatch order.  The figure depends on the dynamic
+    // LDS size; it is looked up once per size class (the size rounded up to 4 KiB).
+    constexpr size_t LDS_CLASS = 4096;
+    constexpr int NCLASS = (int)(((MAX_GROUPS + 1) * sizeof(uint64_t) + LDS_CLASS - 1) / LDS_CLASS) + 1;
+    static long long resident_cache[2][64][NCLASS] = {};
+    const int cls = (int)((lds + LDS_CLASS - 1) / LDS_CLASS);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    long long resident = dev >= 0 && dev < 64 ? resident_cache[STUFF][dev] : 0;
+    long long resident = dev >= 0 && dev < 64 ? resident_cache[STUFF][dev][cls] : 0;
     if (resident == 0) {
         int cus = 0, per_cu = 0;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        // (with the largest dynamic LDS the kernel is ever launched with, so the figure holds for every image)
         if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<STUFF>, ST_THREADS,
-                                                             (MAX_GROUPS + 1) * sizeof(uint64_t));
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<STUFF>, ST_THREADS, (size_t)cls * LDS_CLASS);
         if (e != hipSuccess) return e;
         resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
-        if (dev >= 0 && dev < 64) resident_cache[STUFF][dev] = resident;
+        if (dev >= 0 && dev < 64) resident_cache[STUFF][dev][cls] = resident;
     }
     size_t cap = (size_t)resident;
     if (b.stuff_grid && b.stuff_grid < cap) cap = b.stuff_grid;
