@@ -111,10 +111,13 @@ template <int HS, int VS>
 __device__ __forceinline__ void tile_convert(const uint8_t *__restrict__ src, const Geom &g, int x0, int y0, int mcus,
                                              uint8_t *sY, uint8_t *sCb, uint8_t *sCr, int tid) {
     using C = TileCfg<HS, VS>;
-    if (mcus == C::MCUS && x0 + TILE_W <= g.W && y0 + C::TILE_H <= g.H) {
-        // interior tile: every thread owns ROUNDS items; all loads are issued before the arithmetic
+    const int items_x = mcus * 2 * HS;                       // groups of 4 pixels per row that exist
+    if (x0 + 4 * items_x <= g.W && y0 + C::TILE_H <= g.H) {
+        // every MCU of the tile lies inside the image: every thread owns ROUNDS items (those beyond a
+        // partial tile's last MCU are skipped); all loads are issued before the arithmetic
         uint32_t d[C::ROUNDS][VS][3];
         const int ix = tid & 127;
+        const bool present = ix < items_x;
 #pragma unroll
         for (int k = 0; k < C::ROUNDS; k++) {
             const int iy = 2 * k + (tid >> 7);
@@ -123,26 +126,27 @@ __device__ __forceinline__ void tile_convert(const uint8_t *__restrict__ src, co
                 const int y = y0 + iy * VS + r;
                 const size_t row = (size_t)(g.bottom_up ? g.H - 1 - y : y) * g.stride;
                 const uint32_t *p = reinterpret_cast<const uint32_t *>(src + row + (size_t)3 * (x0 + 4 * ix));
-                d[k][r][0] = p[0]; d[k][r][1] = p[1]; d[k][r][2] = p[2];
+                if (present) { d[k][r][0] = p[0]; d[k][r][1] = p[1]; d[k][r][2] = p[2]; }
             }
         }
+        if (present) {
 #pragma unroll
-        for (int k = 0; k < C::ROUNDS; k++) {
-            const int iy = 2 * k + (tid >> 7);
-            uint32_t cbs[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
+            for (int k = 0; k < C::ROUNDS; k++) {
+                const int iy = 2 * k + (tid >> 7);
+                uint32_t cbs[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int r = 0; r < VS; r++) {
-                uint32_t y4, cb[4], cr[4];
-                convert4(d[k][r][0], d[k][r][1], d[k][r][2], y4, cb, cr);
-                *reinterpret_cast<uint32_t *>(&sY[(iy * VS + r) * TILE_W + 4 * ix]) = y4;
+                for (int r = 0; r < VS; r++) {
+                    uint32_t y4, cb[4], cr[4];
+                    convert4(d[k][r][0], d[k][r][1], d[k][r][2], y4, cb, cr);
+                    *reinterpret_cast<uint32_t *>(&sY[(iy * VS + r) * TILE_W + 4 * ix]) = y4;
 #pragma unroll
-                for (int q = 0; q < 4; q++) { cbs[q] += cb[q]; crs[q] += cr[q]; }
+                    for (int q = 0; q < 4; q++) { cbs[q] += cb[q]; crs[q] += cr[q]; }
+                }
+                store_chroma<HS, VS, C::CW>(sCb, sCr, iy, ix, cbs, crs);
             }
-            store_chroma<HS, VS, C::CW>(sCb, sCr, iy, ix, cbs, crs);
         }
     } else {
-        // edge tile
-        const int items_x = mcus * 2 * HS;
+        // tile cut by the right or bottom edge of the image
         for (int it = tid; it < items_x * 8; it += THREADS) {
             const int ix = it % items_x, iy = it / items_x;
             uint32_t yw[VS], cbs[4], crs[4];
