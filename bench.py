@@ -140,30 +140,35 @@ def main():
     per_launch = min(per_launch, enc.max_batch())
     groups = [imgs[i:i + per_launch] for i in range(0, len(imgs), per_launch)]
 
+    inflight = [0] * len(encs)
+    last = [None]
+
     def step():
-        # Every image's result is taken (sizes read back) before its buffers are reused.  The images of a
-        # group go through one launch of each kernel; a context keeps up to `depth` groups in flight, so the
-        # stuffing of one group overlaps the front kernel of the next.
-        res = None
-        inflight = [0] * len(encs)
+        # The images of a group go through one launch of each kernel; a context keeps up to `depth` groups in
+        # flight, so the stuffing of one group overlaps the coding kernel of the next -- also across steps: a
+        # step queues its groups and takes the results (sizes read back) of the groups queued before them as it
+        # needs their buffers; drain() takes whatever is still in flight before the clock is read.
         for i, g in enumerate(groups):
             k = i % len(encs)
             if inflight[k] == args.depth:
-                res = encs[k].finish_next()
+                last[0] = encs[k].finish_next()
                 inflight[k] -= 1
             if len(g) == 1:
                 encs[k].encode_device_async(g[0].data_ptr(), W, H, stride, True)
             else:
                 encs[k].encode_batch_device_async([t.data_ptr() for t in g], W, H, stride, True)
             inflight[k] += 1
+
+    def drain():
         for k, e in enumerate(encs):
             while inflight[k]:
-                res = e.finish_next()
+                last[0] = e.finish_next()
                 inflight[k] -= 1
-        return res
+        return last[0]
 
     for _ in range(args.warmup):
-        nbits, scan_len = step()
+        step()
+    drain()
 
     def barrier():
         if world > 1:
@@ -178,7 +183,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        nbits, scan_len = step()
+        step()
+    nbits, scan_len = drain()                  # every result of the timed steps has been taken
     barrier()
     dt = time.perf_counter() - t0
     region_ms, region_n, region_images = 0.0, 0, 0
