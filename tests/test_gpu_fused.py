@@ -105,3 +105,49 @@ def test_coefficients_after_device_input(J):
     host.encode_scan(rows, w, h)
     for c in range(3):
         np.testing.assert_array_equal(enc.coeffs(c), host.coeffs(c))
+
+
+@pytest.mark.parametrize("ratio", RATIOS)
+def test_fused_top_down_rows_and_padded_stride(J, oracle, ratio):
+    """Row order and row pitch are the caller's: top-down rows, extra bytes after every row, device-resident
+    rows read in place with that pitch."""
+    import torch
+    w, h = 1096, 83
+    base = J.host.synth_bgr(w, h, seed=21)
+    stride = base.shape[1] + 20
+    rows = np.zeros((h, stride), np.uint8)
+    rows[:, :base.shape[1]] = base
+    dev = torch.from_numpy(rows).cuda()
+    torch.cuda.synchronize()
+    for bottom_up in (True, False):
+        ref = oracle.RefImage.from_bgr(rows, w, h, stride, ratio, oracle.BIN, bottom_up=bottom_up).encode()
+        enc = J.Encoder(ratio, "bin-dct")
+        np.testing.assert_array_equal(enc.encode_scan(rows, w, h, stride, bottom_up), ref.stuffed_scan())
+        assert enc.fused_coding()
+        enc.encode_device_async(dev.data_ptr(), w, h, stride, bottom_up)
+        _, n = enc.finish()
+        np.testing.assert_array_equal(enc.scan(n), ref.stuffed_scan())
+
+
+def test_fused_extreme_content(J, oracle):
+    """Checkerboards and saturated noise at 4:4:4: long blocks, ZRL runs, many 0xFF bytes, tiles of several
+    window passes; the coder's range errors never fire on 8-bit input."""
+    w, h = 1024, 48
+    rng = np.random.default_rng(3)
+    stride = J.host.bmp_stride(w)
+    imgs = []
+    chk = np.zeros((h, stride), np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    chk[:, :3 * w] = np.repeat((((xx + yy) & 1) * 255).astype(np.uint8), 3, axis=1)
+    imgs.append(chk)
+    sat = np.zeros((h, stride), np.uint8)
+    sat[:, :3 * w] = rng.choice(np.array([0, 255], np.uint8), size=(h, 3 * w))
+    imgs.append(sat)
+    imp = np.zeros((h, stride), np.uint8)
+    imp[::8, 21:3 * w:24] = 255
+    imgs.append(imp)
+    for rows in imgs:
+        for algo, ref_algo in (("bin-dct", oracle.BIN), ("real-dct-strict", oracle.REAL)):
+            ref = oracle.RefImage.from_bgr(rows, w, h, stride, (4, 4, 4), ref_algo).encode()
+            enc = J.Encoder((4, 4, 4), algo)
+            np.testing.assert_array_equal(enc.encode_scan(rows, w, h), ref.stuffed_scan())
