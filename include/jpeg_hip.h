@@ -101,7 +101,11 @@ int jpg_stuff(jpg_ctx *ctx, size_t *len);
 int jpg_front_device(jpg_ctx *ctx, const uint8_t *dev_pixels, int32_t width, int32_t height,
                      uint32_t row_stride, int bottom_up);
 /* the same from host memory: the rows are copied to the device first (the copy
- * is complete when the call returns, so `pixels` may be reused) */
+ * is complete when the call returns, so `pixels` may be reused).  For images at
+ * least 512 pixels wide the transform itself is deferred to the call that tells
+ * what is wanted: jpg_get_coeffs runs the kernel above, jpg_entropy /
+ * jpg_entropy_stripe code the rows in one kernel without writing coefficients,
+ * jpg_last_dc transforms the last MCU only. */
 int jpg_front_host(jpg_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t height, uint32_t row_stride,
                    int bottom_up);
 /* A whole encode from device-resident rows to the stuffed scan, queued without any host

@@ -584,19 +584,32 @@ static int make_dense(jpg_ctx *c) {
 
 // The fused coding kernel leaves no coefficients behind.  When they are asked for afterwards they are
 // computed from the context's own copy of the rows; rows the caller owns may be gone by then.
+static bool own_rows(const jpg_ctx *c) { return c->nimg == 1 && c->d_src && c->d_src == c->d_src_own; }
+
 static int need_coef(jpg_ctx *c) {
     if (c->coef_valid) return JPG_OK;
-    if (c->nimg != 1 || !c->d_src || c->d_src != c->d_src_own) return JPG_ERR_STATE;
+    if (!own_rows(c)) return JPG_ERR_STATE;
     return queue_front(c);
+}
+
+// may the current image be coded straight from the context's copy of its rows?
+static bool code_from_rows(const jpg_ctx *c) {
+    return !c->coef_valid && own_rows(c) && !c->two_kernels && coded_supported(c->g);
 }
 
 static int entropy_common(jpg_ctx *c, const int16_t *pred, uint64_t *nbits) {
     if (!c) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_COEF) return JPG_ERR_STATE;
     if (int e = use_device(c)) return e;
-    if (int e = need_coef(c)) return e;
     c->npend = 0;
-    if (int e = queue_entropy(c, pred)) return e;
+    if (code_from_rows(c)) {
+        // no coefficients were asked for so far: one kernel from the rows to the coded tiles
+        if (int e = prepare_slot(c, true)) return e;
+        HIP_TRY(c, launch_coded(c->g, c->algo, c->d_src, nullptr, 1, pred ? pred : ZERO_PRED, S(c).eb, c->stream));
+    } else {
+        if (int e = need_coef(c)) return e;
+        if (int e = queue_entropy(c, pred)) return e;
+    }
     if (int e = make_dense(c)) return e;
     jpg_ctx::Slot &sl = S(c);
     if (int ke = kernel_error(sl)) return ke;
@@ -638,8 +651,12 @@ extern "C" int jpg_last_dc(jpg_ctx *c, int16_t dc[3]) {
     if (!c || !dc) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_COEF) return JPG_ERR_STATE;
     if (int e = use_device(c)) return e;
-    if (int e = need_coef(c)) return e;
-    HIP_TRY(c, launch_last_dc(c->g, c->d_coef, c->d_dc, c->stream));
+    if (code_from_rows(c)) {
+        HIP_TRY(c, launch_last_dc_pixels(c->g, c->algo, c->d_src, c->d_dc, c->stream));
+    } else {
+        if (int e = need_coef(c)) return e;
+        HIP_TRY(c, launch_last_dc(c->g, c->d_coef, c->d_dc, c->stream));
+    }
     HIP_TRY(c, hipMemcpyAsync(c->h_dc, c->d_dc, 3 * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     dc[0] = c->h_dc[0]; dc[1] = c->h_dc[1]; dc[2] = c->h_dc[2];
@@ -680,7 +697,11 @@ extern "C" int jpg_front_host(jpg_ctx *c, const uint8_t *pixels, int32_t W, int3
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
     if (int e = stage_input(c, pixels, true)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // caller may reuse `pixels`
-    if (int e = queue_front(c)) return e;
+    // The context now holds its own copy of the rows.  Where the single coding kernel applies, the
+    // transform waits for the call that tells what is wanted: coefficients (jpg_get_coeffs: front kernel)
+    // or bits (jpg_entropy, jpg_entropy_stripe: coding kernel, no coefficients in memory).
+    if (!c->two_kernels && coded_supported(c->g)) c->coef_valid = false;
+    else if (int e = queue_front(c)) return e;
     c->stage = ST_COEF;
     return JPG_OK;
 }

@@ -180,6 +180,44 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
     }
 }
 
+// The DC coefficients of the last Y, Cb, Cr blocks of MCU (mx, my), straight from the pixels: what a
+// following stripe starts its predictors from (src/jpeg/entropy_coding.rs:149-150).  One wave.
+template <int HS, int VS, int ALGO>
+__global__ __launch_bounds__(64) void k_mcu_dc(const uint8_t *__restrict__ src, Geom g, int mx, int my,
+                                               int16_t *__restrict__ dc3) {
+    using C = TileCfg<HS, VS>;
+    __shared__ __attribute__((aligned(16))) uint8_t sHalo[C::HALO_BYTES];
+    __shared__ int16_t sDc[4];
+    const int lane = threadIdx.x;
+    HaloRegs<VS> regs;
+    halo_load<HS, VS>(src, g, mx * 8 * HS, my * 8 * VS, lane, regs);
+    halo_convert<HS, VS>(src, g, mx * 8 * HS, my * 8 * VS, sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, regs);
+    __builtin_amdgcn_wave_barrier();   // (the LDS accesses of one wave execute in order)
+    halo_dc<HS, VS, ALGO>(sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, sDc);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 3) dc3[lane] = sDc[lane];
+}
+
+template <int HS, int VS>
+static hipError_t launch_mcu_dc_hv(const Geom &g, int algo, const uint8_t *src, int16_t *dc3, hipStream_t s) {
+    const int mx = g.mcux - 1, my = g.mcuy - 1;
+    switch (algo) {
+        case ALGO_REAL: hipLaunchKernelGGL((k_mcu_dc<HS, VS, ALGO_REAL>), dim3(1), dim3(64), 0, s, src, g, mx, my, dc3); break;
+        case ALGO_BIN: hipLaunchKernelGGL((k_mcu_dc<HS, VS, ALGO_BIN>), dim3(1), dim3(64), 0, s, src, g, mx, my, dc3); break;
+        case ALGO_REAL_STRICT: hipLaunchKernelGGL((k_mcu_dc<HS, VS, ALGO_REAL_STRICT>), dim3(1), dim3(64), 0, s, src, g, mx, my, dc3); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_last_dc_pixels(const Geom &g, int algo, const uint8_t *src, int16_t *dc3, hipStream_t s) {
+    if ((reinterpret_cast<uintptr_t>(src) & 3) || (g.stride & 3)) return hipErrorInvalidValue;
+    if (g.h == 2 && g.v == 2) return launch_mcu_dc_hv<2, 2>(g, algo, src, dc3, s);
+    if (g.h == 2 && g.v == 1) return launch_mcu_dc_hv<2, 1>(g, algo, src, dc3, s);
+    if (g.h == 1 && g.v == 1) return launch_mcu_dc_hv<1, 1>(g, algo, src, dc3, s);
+    return hipErrorInvalidValue;
+}
+
 template <int HS, int VS>
 static hipError_t launch_coded_hv(const CodedArgs &a, int algo, int nimg, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     using C = TileCfg<HS, VS>;

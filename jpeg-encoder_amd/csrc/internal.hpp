@@ -104,6 +104,8 @@ int coded_slot_words(const Geom &g);
 hipError_t launch_coded(const Geom &g, int algo, const uint8_t *src, const uint8_t *const *srcs, int nimg,
                         const int16_t pred[3], const EntropyBufs &b, hipStream_t s, hipEvent_t e0 = nullptr,
                         hipEvent_t e1 = nullptr);
+// the DC coefficients of the last Y, Cb, Cr blocks of the image, computed from its pixels
+hipError_t launch_last_dc_pixels(const Geom &g, int algo, const uint8_t *src, int16_t *dc3, hipStream_t s);
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s);
 // writes the dense stream to b.bits
 hipError_t launch_dense(const EntropyBufs &b, hipStream_t s);

@@ -151,3 +151,32 @@ def test_fused_extreme_content(J, oracle):
             ref = oracle.RefImage.from_bgr(rows, w, h, stride, (4, 4, 4), ref_algo).encode()
             enc = J.Encoder((4, 4, 4), algo)
             np.testing.assert_array_equal(enc.encode_scan(rows, w, h), ref.stuffed_scan())
+
+
+@pytest.mark.parametrize("ratio,algo,w,h,n", [
+    ((4, 2, 0), "bin-dct", 1032, 200, 3), ((4, 2, 2), "real-dct-strict", 640, 120, 4), ((4, 4, 4), "bin-dct", 1544, 70, 5),
+])
+def test_stripes_through_the_fused_kernel(J, oracle, ratio, algo, w, h, n):
+    """Stripes of host rows: the rows wait in the context until the stripe is coded, in one kernel, from the
+    predictors the stripes above hand over; the last DCs come from the last MCU's pixels."""
+    import torch
+    S = J.stripes
+    rows = J.host.synth_bgr(w, h, seed=17, noise_only=True)
+    stride = rows.shape[1]
+    _, v = J.get_downsampling_factor(ratio)
+    jobs = [S.StripeJob(J.Encoder(ratio, algo), k, n, rows, w, h, stride, v) for k in range(n)]
+    dcs = [j.transform() for j in jobs]
+    # the same values from the coefficients of a front-kernel run over device-resident rows
+    for j, got in zip(jobs, dcs):
+        sub = np.ascontiguousarray(S.stripe_rows(rows, h, j.y0, j.y1))
+        t = torch.from_numpy(sub).cuda()
+        torch.cuda.synchronize()
+        enc = J.Encoder(ratio, algo)
+        enc.front_device(t.data_ptr(), w, j.y1 - j.y0, stride, True)
+        assert tuple(enc.last_dc()) == tuple(got)
+        enc.sync()
+    codes = [j.code(dcs) for j in jobs]
+    pieces = [j.place(codes) for j in jobs]
+    want = oracle.RefImage.from_bgr(rows, w, h, stride, ratio, oracle.BIN if algo == "bin-dct" else oracle.REAL).encode()
+    assert sum(c[0] for c in codes) == want.bits()[1]
+    np.testing.assert_array_equal(np.concatenate(pieces), want.stuffed_scan())
