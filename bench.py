@@ -101,6 +101,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-process path on a box with one GPU: every rank on device 0, gloo for the barrier
+    rehearsal = os.environ.get("BENCH_REHEARSAL_ONE_GPU") == "1"
+    if rehearsal:
+        local = 0
 
     import numpy as np
     import torch
@@ -111,7 +115,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     ratio = tuple(int(x) for x in args.ratio.split(":"))
     W, H = args.width, args.height
@@ -195,7 +202,7 @@ def main():
         region_images += im
         e.set_timing(0)
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
