@@ -210,7 +210,8 @@ uint64_t jpg_front_bytes(const jpg_ctx *ctx);
 /* number of 8x8 blocks (all components) of the current image */
 uint64_t jpg_num_blocks(const jpg_ctx *ctx);
 /* 1 when whole encodes of the current image size run the single fused coding kernel (which reads
- * row_stride*H bytes and writes only the coded bits), 0 when they run front + entropy kernels */
+ * row_stride*H bytes and writes only the coded bits), 0 when they run front + entropy kernels.
+ * No counterpart in the reference. */
 int jpg_fused_coding(const jpg_ctx *ctx);
 
 #ifdef __cplusplus
