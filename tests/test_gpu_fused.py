@@ -180,3 +180,19 @@ def test_stripes_through_the_fused_kernel(J, oracle, ratio, algo, w, h, n):
     want = oracle.RefImage.from_bgr(rows, w, h, stride, ratio, oracle.BIN if algo == "bin-dct" else oracle.REAL).encode()
     assert sum(c[0] for c in codes) == want.bits()[1]
     np.testing.assert_array_equal(np.concatenate(pieces), want.stuffed_scan())
+
+
+@pytest.mark.parametrize("ratio", RATIOS)
+def test_fused_flat_image_many_tiles_per_segment(J, oracle, ratio):
+    """A black image codes to the minimum number of bits per block, so a 4 KiB segment of the stream spans
+    as many tile slots as it ever can (full tiles alternating with a one-MCU tile)."""
+    w, h = 2048 + 16, 1600
+    stride = J.host.bmp_stride(w)
+    rows = np.zeros((h, stride), np.uint8)
+    ref = oracle.RefImage.from_bgr(rows, w, h, stride, ratio, oracle.BIN).encode(threads=3)
+    enc = J.Encoder(ratio, "bin-dct")
+    scan = enc.encode_scan(rows, w, h)
+    assert enc.fused_coding()
+    np.testing.assert_array_equal(scan, ref.stuffed_scan())
+    bits, nbits = ref.bits()
+    np.testing.assert_array_equal(enc.bits(nbits), bits)
