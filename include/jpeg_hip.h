@@ -102,14 +102,14 @@ int jpg_front_device(jpg_ctx *ctx, const uint8_t *dev_pixels, int32_t width, int
                      uint32_t row_stride, int bottom_up);
 /* the same from host memory: the rows are copied to the device first (the copy
  * is complete when the call returns, so `pixels` may be reused).  For images at
- * least 512 pixels wide the transform itself is deferred to the call that tells
+ * least one tile wide the transform itself is deferred to the call that tells
  * what is wanted: jpg_get_coeffs runs the kernel above, jpg_entropy /
  * jpg_entropy_stripe code the rows in one kernel without writing coefficients,
  * jpg_last_dc transforms the last MCU only. */
 int jpg_front_host(jpg_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t height, uint32_t row_stride,
                    int bottom_up);
 /* A whole encode from device-resident rows to the stuffed scan, queued without any host
- * synchronisation; jpg_finish() waits and reports.  Images at least one tile (512 pixels) wide go
+ * synchronisation; jpg_finish() waits and reports.  Images at least one tile (512 pixels, 1024 at 4:2:2) wide go
  * through ONE kernel from pixels to Huffman-coded bits (no coefficient ever reaches memory) plus the
  * stuffing kernel; narrower ones through the front kernel, the entropy kernel and the stuffing
  * kernel (also for every image when the environment variable JPG_TWO_KERNELS=1 is set at

@@ -6,7 +6,7 @@
 // (src/jpeg/dct_quant.rs:15-61) and generate_entropy_encoded_data
 // (src/jpeg/entropy_coding.rs:16-125) of the reference.
 //
-// One workgroup owns a tile of 512 pixels x one MCU row, converts and transforms
+// One workgroup owns a tile of 512 (4:2:2: 1024) pixels x one MCU row, converts and transforms
 // it (tile.hpp) and then codes the tile's blocks, which are consecutive in the
 // scan: one thread per block measures its block, a scan over the workgroup
 // places it, and the bits are assembled in LDS and stored to the tile's own
@@ -17,8 +17,8 @@
 // component before it (the three predictor chains of
 // src/jpeg/entropy_coding.rs:38-40,149-150).  Instead of waiting for the tile
 // before it, the workgroup converts that one MCU again and computes the three DC
-// coefficients (the fourth wave does it while the other three transform the
-// tile's blocks), so that no workgroup depends on another.
+// coefficients (the fourth wave does it; except at 4:2:2 it has no block of the
+// tile to transform), so that no workgroup depends on another.
 #include <hip/hip_ext.h>
 
 #include "coding.hpp"
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
     __shared__ uint32_t sWin[WIN_WORDS + 2];
     __shared__ uint32_t sTot[THREADS / 64], sPass[THREADS / 64];
     uint8_t *sY = lds;
-    uint8_t *sCb = lds + C::TILE_H * TILE_W;
+    uint8_t *sCb = lds + C::TILE_H * C::TW;
     uint8_t *sCr = sCb + 8 * C::CW;
     const Geom &g = a.g;
 
@@ -235,7 +235,7 @@ static hipError_t launch_coded_hv(const CodedArgs &a, int algo, int nimg, hipStr
     return hipGetLastError();
 }
 
-static int tile_mcus(const Geom &g) { return TILE_W / (8 * g.h); }
+static int tile_mcus(const Geom &g) { return tile_width(g.h, g.v) / (8 * g.h); }
 
 bool coded_supported(const Geom &g) {
     // Every row of tiles must begin with a full tile: the stream kernels tabulate a bounded number of

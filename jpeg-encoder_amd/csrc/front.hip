@@ -5,7 +5,7 @@
 // (src/jpeg/sampling.rs:46-102) and dct_and_quantization
 // (src/jpeg/dct_quant.rs:15-61) of the reference.
 //
-// One workgroup owns a tile of 512 pixels x one MCU row (8*v image rows): it
+// One workgroup owns a tile of 512 (4:2:2: 1024) pixels x one MCU row (8*v image rows): it
 // converts and transforms the tile (tile.hpp); the tile's blocks, contiguous in
 // the scan layout, then go to global memory as coalesced 16-byte stores.
 // HBM traffic is the algorithmic minimum: every input byte is read once, every
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(THREADS) void k_front(const uint8_t *__restrict__ s
     // Y plane, then Cb, Cr planes of the tile; phase B reuses the space for the finished blocks
     __shared__ __attribute__((aligned(16))) uint8_t lds[C::LDS_BYTES];
     uint8_t *sY = lds;
-    uint8_t *sCb = lds + C::TILE_H * TILE_W;
+    uint8_t *sCb = lds + C::TILE_H * C::TW;
     uint8_t *sCr = sCb + 8 * C::CW;
 
     const int tiles_x = (g.mcux + C::MCUS - 1) / C::MCUS;

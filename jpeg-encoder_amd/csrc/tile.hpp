@@ -1,6 +1,6 @@
 // One tile of the fused front end, shared by k_front (front.hip: coefficients to
 // memory) and k_coded (coded.hip: coefficients straight into the entropy coder).
-// A tile is 512 pixels x one MCU row (8*v image rows):
+// A tile is 512 pixels (1024 at 4:2:2) x one MCU row (8*v image rows):
 //   tile_convert    every thread converts groups of 4 pixels x v rows read straight
 //                   from global memory (12 contiguous bytes per row and lane, so a
 //                   wave reads 768 contiguous bytes) and leaves Y and the averaged
@@ -16,29 +16,36 @@
 
 namespace jpg {
 
-constexpr int TILE_W = 512;     // pixels per tile row
+// Pixels per tile row.  At 4:2:2 an MCU row is only 8 pixel rows high: the wider tile gives the workgroup
+// as many pixels (8192) and blocks (256, one per thread) as it takes to keep all four waves busy.
+__host__ __device__ constexpr int tile_width(int hs, int vs) { return hs == 2 && vs == 1 ? 1024 : 512; }
 constexpr int OUT_STRIDE = 144; // bytes between parked blocks in LDS (128 + 16: conflict-free b128 access)
 constexpr int THREADS = 256;
 
 template <int HS, int VS>
 struct TileCfg {
-    static constexpr int MCUS = TILE_W / (8 * HS);           // MCUs per tile
+    static constexpr int TW = tile_width(HS, VS);             // pixels per tile row
+    static constexpr int MCUS = TW / (8 * HS);                // MCUs per tile
     static constexpr int NBLK = HS * VS + 2;                  // blocks per MCU
     static constexpr int TILE_H = 8 * VS;                     // image rows per tile
-    static constexpr int YWAVES = VS;                         // 64 luma blocks per block row
+    static constexpr int ROW_WAVES = TW / 512;                // waves per row of luma blocks (64 blocks each)
+    static constexpr int YWAVES = VS * ROW_WAVES;
     static constexpr int CWAVES = (2 * MCUS) / 64;            // chroma blocks: MCUS per component
-    static constexpr int CW = TILE_W / HS;                    // chroma samples per tile row
+    static constexpr int CW = TW / HS;                        // chroma samples per tile row
     static constexpr int BLOCKS = MCUS * NBLK;
-    static constexpr int ITEMS = (TILE_W / 4) * 8;            // groups of 4 pixels x VS rows
+    static constexpr int ROW_ITEMS = TW / 4;                  // groups of 4 pixels per row
+    static constexpr int ITEMS = ROW_ITEMS * 8;               // groups of 4 pixels x VS rows
+    static constexpr int ROUND_ROWS = THREADS / ROW_ITEMS;    // item rows the threads cover per round
     static constexpr int ROUNDS = ITEMS / THREADS;            // items per thread in a full tile
-    static constexpr int PLANE_BYTES = TILE_H * TILE_W + 2 * 8 * CW;
+    static constexpr int PLANE_BYTES = TILE_H * TW + 2 * 8 * CW;
     static constexpr int OUT_BYTES = BLOCKS * OUT_STRIDE;
     static constexpr int LDS_BYTES = PLANE_BYTES > OUT_BYTES ? PLANE_BYTES : OUT_BYTES;
     // the planes of one more MCU (k_coded: the MCU before the tile)
     static constexpr int HALO_Y = 64 * HS * VS;               // bytes of its luma samples
     static constexpr int HALO_BYTES = HALO_Y + 2 * 64;
-    static constexpr int SPARE_WAVE = THREADS / 64 - 1;       // the wave with no block of the tile to transform
-    static_assert(YWAVES + CWAVES <= SPARE_WAVE, "one thread per block, one wave to spare");
+    static constexpr int SPARE_WAVE = THREADS / 64 - 1;       // the wave that takes the extra work: it has no block of
+                                                              // the tile to transform, except at 4:2:2
+    static_assert(YWAVES + CWAVES <= THREADS / 64 && BLOCKS <= THREADS, "one thread per block");
     static_assert(ITEMS % THREADS == 0, "whole rounds");
 };
 
@@ -105,7 +112,7 @@ __device__ __forceinline__ void convert_item_edge(const uint8_t *src, const Geom
     }
 }
 
-// Colour conversion + chroma average of the tile at (x0, y0) with `mcus` MCUs into sY (TILE_W
+// Colour conversion + chroma average of the tile at (x0, y0) with `mcus` MCUs into sY (TW
 // bytes per row), sCb, sCr (CW bytes per row).
 template <int HS, int VS>
 __device__ __forceinline__ void tile_convert(const uint8_t *__restrict__ src, const Geom &g, int x0, int y0, int mcus,
@@ -116,11 +123,11 @@ __device__ __forceinline__ void tile_convert(const uint8_t *__restrict__ src, co
         // every MCU of the tile lies inside the image: every thread owns ROUNDS items (those beyond a
         // partial tile's last MCU are skipped); all loads are issued before the arithmetic
         uint32_t d[C::ROUNDS][VS][3];
-        const int ix = tid & 127;
+        const int ix = tid % C::ROW_ITEMS;
         const bool present = ix < items_x;
 #pragma unroll
         for (int k = 0; k < C::ROUNDS; k++) {
-            const int iy = 2 * k + (tid >> 7);
+            const int iy = C::ROUND_ROWS * k + tid / C::ROW_ITEMS;
 #pragma unroll
             for (int r = 0; r < VS; r++) {
                 const int y = y0 + iy * VS + r;
@@ -132,13 +139,13 @@ __device__ __forceinline__ void tile_convert(const uint8_t *__restrict__ src, co
         if (present) {
 #pragma unroll
             for (int k = 0; k < C::ROUNDS; k++) {
-                const int iy = 2 * k + (tid >> 7);
+                const int iy = C::ROUND_ROWS * k + tid / C::ROW_ITEMS;
                 uint32_t cbs[4] = {0, 0, 0, 0}, crs[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int r = 0; r < VS; r++) {
                     uint32_t y4, cb[4], cr[4];
                     convert4(d[k][r][0], d[k][r][1], d[k][r][2], y4, cb, cr);
-                    *reinterpret_cast<uint32_t *>(&sY[(iy * VS + r) * TILE_W + 4 * ix]) = y4;
+                    *reinterpret_cast<uint32_t *>(&sY[(iy * VS + r) * C::TW + 4 * ix]) = y4;
 #pragma unroll
                     for (int q = 0; q < 4; q++) { cbs[q] += cb[q]; crs[q] += cr[q]; }
                 }
@@ -152,7 +159,7 @@ __device__ __forceinline__ void tile_convert(const uint8_t *__restrict__ src, co
             uint32_t yw[VS], cbs[4], crs[4];
             convert_item_edge<VS>(src, g, x0 + 4 * ix, y0 + iy * VS, yw, cbs, crs);
 #pragma unroll
-            for (int r = 0; r < VS; r++) *reinterpret_cast<uint32_t *>(&sY[(iy * VS + r) * TILE_W + 4 * ix]) = yw[r];
+            for (int r = 0; r < VS; r++) *reinterpret_cast<uint32_t *>(&sY[(iy * VS + r) * C::TW + 4 * ix]) = yw[r];
             store_chroma<HS, VS, C::CW>(sCb, sCr, iy, ix, cbs, crs);
         }
     }
@@ -226,28 +233,29 @@ __device__ __forceinline__ void halo_dc(const uint8_t *hY, const uint8_t *hCb, c
 
 // One thread per block: samples from the planes at the start of `lds` into registers, then (the
 // planes' space being reused) the finished blocks to lds[bi * OUT_STRIDE], bi = position of the block
-// in the scan order of the tile.  The last wave has no block to transform: it runs spare() meanwhile.
+// in the scan order of the tile.  The last wave also runs spare(); except at 4:2:2 it has no block to transform.
 // Contains one barrier; the caller places one after it.
 template <int HS, int VS, int ALGO, class Spare>
 __device__ __forceinline__ void tile_transform(uint8_t *lds, int mcus, int tid, Spare spare) {
     using C = TileCfg<HS, VS>;
     const uint8_t *sY = lds;
-    const uint8_t *sCb = lds + C::TILE_H * TILE_W;
+    const uint8_t *sCb = lds + C::TILE_H * C::TW;
     const uint8_t *sCr = sCb + 8 * C::CW;
     const int wave = tid >> 6, lane = tid & 63;
     uint32_t px[16];
     int bi = -1;                                               // block index inside the tile, scan order
     if (wave < C::YWAVES) {
-        // luma: block row `wave`, block column `lane` of the tile
-        const int m = lane / HS;                               // MCU inside the tile
+        // luma: block row `brow`, block column `bcol` of the tile
+        const int brow = wave / C::ROW_WAVES, bcol = (wave % C::ROW_WAVES) * 64 + lane;
+        const int m = bcol / HS;                               // MCU inside the tile
         if (m < mcus) {
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(&sY[(wave * 8 + r) * TILE_W + lane * 8]);
+                const uint2 v = *reinterpret_cast<const uint2 *>(&sY[(brow * 8 + r) * C::TW + bcol * 8]);
                 px[2 * r] = v.x;
                 px[2 * r + 1] = v.y;
             }
-            bi = m * C::NBLK + wave * HS + (lane % HS);
+            bi = m * C::NBLK + brow * HS + (bcol % HS);
         }
     } else if (wave < C::YWAVES + C::CWAVES) {
         const int ci = (wave - C::YWAVES) * 64 + lane;         // 0 .. 2*MCUS-1

@@ -14,6 +14,11 @@ REF_ALGO = {"real-dct-strict": "REAL", "bin-dct": "BIN"}   # names of the oracle
 SIZES = [(512, 16), (1000, 37), (1544, 72), (2048 + 24, 40)]
 
 
+def tile_width(ratio):
+    """Pixels per tile; images at least that wide go through the fused coding kernel."""
+    return 1024 if tuple(ratio) == (4, 2, 2) else 512
+
+
 @pytest.fixture()
 def two_kernel_encoder(J):
     """Encoder factory whose contexts never use the fused coding kernel."""
@@ -37,7 +42,7 @@ def test_fused_coding_matches_oracle_and_two_kernels(J, oracle, two_kernel_encod
         ref.encode()
         enc = J.Encoder(ratio, algo)
         scan = enc.encode_scan(rows, w, h)
-        assert enc.fused_coding()
+        assert enc.fused_coding() == (w >= tile_width(ratio))
         np.testing.assert_array_equal(scan, ref.stuffed_scan(), err_msg="%s scan" % algo)
         want_bits, want_nbits = ref.bits()
         nbits = want_nbits
@@ -59,6 +64,11 @@ def test_narrow_images_keep_the_kernel_pair(J):
     assert not enc.fused_coding()
     enc = J.Encoder((4, 4, 4), "bin-dct")
     enc.encode_scan(J.host.synth_bgr(512, 8, 5), 512, 8)
+    assert enc.fused_coding()
+    enc = J.Encoder((4, 2, 2), "bin-dct")                        # 4:2:2 tiles are 1024 pixels wide
+    enc.encode_scan(J.host.synth_bgr(1008, 8, 5), 1008, 8)
+    assert not enc.fused_coding()
+    enc.encode_scan(J.host.synth_bgr(1024, 8, 5), 1024, 8)
     assert enc.fused_coding()
 
 
@@ -154,7 +164,7 @@ def test_fused_extreme_content(J, oracle):
 
 
 @pytest.mark.parametrize("ratio,algo,w,h,n", [
-    ((4, 2, 0), "bin-dct", 1032, 200, 3), ((4, 2, 2), "real-dct-strict", 640, 120, 4), ((4, 4, 4), "bin-dct", 1544, 70, 5),
+    ((4, 2, 0), "bin-dct", 1032, 200, 3), ((4, 2, 2), "real-dct-strict", 1040, 120, 4), ((4, 4, 4), "bin-dct", 1544, 70, 5),
 ])
 def test_stripes_through_the_fused_kernel(J, oracle, ratio, algo, w, h, n):
     """Stripes of host rows: the rows wait in the context until the stripe is coded, in one kernel, from the
