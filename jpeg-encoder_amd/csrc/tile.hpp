@@ -19,6 +19,10 @@ namespace jpg {
 // Pixels per tile row.  At 4:2:2 an MCU row is only 8 pixel rows high: the wider tile gives the workgroup
 // as many pixels (8192) and blocks (256, one per thread) as it takes to keep all four waves busy.
 __host__ __device__ constexpr int tile_width(int hs, int vs) { return hs == 2 && vs == 1 ? 1024 : 512; }
+// Pixel rows are device memory whatever the pointer's static type says (a pointer read from a struct or an
+// array is "generic" to the compiler, which then emits flat loads that also count as LDS operations).
+typedef const __attribute__((address_space(1))) uint32_t *global_u32_ptr;
+typedef const __attribute__((address_space(1))) uint8_t *global_u8_ptr;
 constexpr int OUT_STRIDE = 144; // bytes between parked blocks in LDS (128 + 16: conflict-free b128 access)
 constexpr int THREADS = 256;
 
@@ -97,11 +101,11 @@ __device__ __forceinline__ void convert_item_edge(const uint8_t *src, const Geom
         const int y = ytop + r;
         uint32_t yy[4] = {0, 0, 0, 0};
         if (y < g.H) {
-            const uint8_t *p = src + (size_t)(g.bottom_up ? g.H - 1 - y : y) * g.stride;
+            const global_u8_ptr p = (global_u8_ptr)(src + (size_t)(g.bottom_up ? g.H - 1 - y : y) * g.stride);
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (x + q < g.W) {
-                    const uint8_t *c = p + (size_t)3 * (x + q);
+                    const global_u8_ptr c = p + (size_t)3 * (x + q);
                     uint32_t cb, cr;
                     rgb_to_ycbcr((float)c[2], (float)c[1], (float)c[0], yy[q], cb, cr);
                     cbs[q] += cb;
@@ -125,14 +129,21 @@ __device__ __forceinline__ void tile_convert(const uint8_t *__restrict__ src, co
         uint32_t d[C::ROUNDS][VS][3];
         const int ix = tid % C::ROW_ITEMS;
         const bool present = ix < items_x;
+        // Addresses are a base that is the same for the whole workgroup (scalar registers) plus a 32-bit
+        // offset per lane: the item row of this thread within a round (the later row lies lower in a
+        // bottom-up file) and the 12 bytes per item.
+        const int sub = tid / C::ROW_ITEMS;                     // 0 .. ROUND_ROWS-1
+        const uint32_t lane_off = 12u * (uint32_t)ix +
+                                  (uint32_t)(g.bottom_up ? C::ROUND_ROWS - 1 - sub : sub) * (uint32_t)VS * g.stride;
 #pragma unroll
         for (int k = 0; k < C::ROUNDS; k++) {
-            const int iy = C::ROUND_ROWS * k + tid / C::ROW_ITEMS;
 #pragma unroll
             for (int r = 0; r < VS; r++) {
-                const int y = y0 + iy * VS + r;
-                const size_t row = (size_t)(g.bottom_up ? g.H - 1 - y : y) * g.stride;
-                const uint32_t *p = reinterpret_cast<const uint32_t *>(src + row + (size_t)3 * (x0 + 4 * ix));
+                // row of sub-row 0 (top-down) or of the last sub-row (bottom-up): the lowest address of the round
+                const int y = y0 + C::ROUND_ROWS * k * VS + r;
+                const size_t row = g.bottom_up ? (size_t)(g.H - 1 - y - (C::ROUND_ROWS - 1) * VS) : (size_t)y;
+                const uint8_t *base = src + row * g.stride + (size_t)3 * x0;
+                const global_u32_ptr p = (global_u32_ptr)(base + lane_off);
                 if (present) { d[k][r][0] = p[0]; d[k][r][1] = p[1]; d[k][r][2] = p[2]; }
             }
         }
@@ -186,7 +197,7 @@ __device__ __forceinline__ void halo_load(const uint8_t *__restrict__ src, const
         if (h.full) {
             const int y = ytop + r;
             const size_t row = (size_t)(g.bottom_up ? g.H - 1 - y : y) * g.stride;
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(src + row + (size_t)3 * x);
+            const global_u32_ptr p = (global_u32_ptr)(src + row + (size_t)3 * x);
             h.d[r][0] = p[0]; h.d[r][1] = p[1]; h.d[r][2] = p[2];
         }
     }
