@@ -1,0 +1,93 @@
+"""Randomised parity run on the GPU box: random sizes, ratios, transforms, contents, row orders, pitches and
+input kinds (host rows, device rows, batches, stripes) through the C ABI, every stuffed scan compared byte for byte with
+the CPU oracle.  usage: python tools/fuzz_parity.py [cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import jpeg_encoder_amd as J  # noqa: E402
+from oracle import refcpu  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+RATIOS = [(4, 4, 4), (4, 2, 2), (4, 2, 0)]
+ALGOS = [("bin-dct", refcpu.BIN), ("real-dct-strict", refcpu.REAL)]
+encs = {}
+
+
+def content(w, h, kind, stride):
+    rows = np.zeros((h, stride), np.uint8)
+    if kind == 0:
+        rows[:, :3 * w] = J.host.synth_bgr(w, h, int(rng.integers(1 << 30)))[:, :3 * w]
+    elif kind == 1:
+        rows[:, :3 * w] = rng.integers(0, 256, (h, 3 * w), dtype=np.uint8)
+    elif kind == 2:
+        rows[:, :3 * w] = rng.choice(np.array([0, 255], np.uint8), size=(h, 3 * w))
+    elif kind == 3:
+        m = rng.random((h, 3 * w)) < 0.01
+        rows[:, :3 * w][m] = 255
+    else:
+        rows[:, :3 * w] = int(rng.integers(256))
+    return rows
+
+
+t0 = time.time()
+done = fused = 0
+for it in range(cases):
+    ratio = RATIOS[int(rng.integers(3))]
+    algo, ref_algo = ALGOS[int(rng.integers(2))]
+    wide = rng.random() < 0.6
+    w = int(rng.integers(512, 2600)) if wide else int(rng.integers(1, 512))
+    h = int(rng.integers(1, 120 if wide else 400))
+    hs, vs = J.get_downsampling_factor(ratio)
+    if (hs == 2 and w % 16 == 1) or (vs == 2 and h % 16 == 1):
+        w += 1 if hs == 2 and w % 16 == 1 else 0
+        h += 1 if vs == 2 and h % 16 == 1 else 0
+    stride = J.host.bmp_stride(w) + 4 * int(rng.integers(0, 4)) + (int(rng.integers(0, 4)) if rng.random() < 0.2 else 0)
+    bottom_up = bool(rng.integers(2))
+    kind = int(rng.integers(5))
+    rows = content(w, h, kind, stride)
+    want = refcpu.RefImage.from_bgr(rows, w, h, stride, ratio, ref_algo, bottom_up=bottom_up).encode().stuffed_scan()
+    enc = encs.setdefault((ratio, algo), J.Encoder(ratio, algo))
+    mode = int(rng.integers(4))
+    if mode == 3:
+        # MCU-row stripes on separate contexts, stitched
+        n = int(rng.integers(2, 6))
+        jobs = [J.stripes.StripeJob(J.Encoder(ratio, algo), k, n, rows, w, h, stride, vs, bottom_up) for k in range(n)]
+        dcs = [j.transform() for j in jobs]
+        codes = [j.code(dcs) for j in jobs]
+        got = np.concatenate([j.place(codes) for j in jobs])
+        for j in jobs:
+            j.backend.close()
+    elif mode == 0 or stride % 4:
+        got = enc.encode_scan(rows, w, h, stride, bottom_up)
+    elif mode == 1:
+        t = torch.from_numpy(rows).cuda()
+        torch.cuda.synchronize()
+        enc.encode_device_async(t.data_ptr(), w, h, stride, bottom_up)
+        _, n = enc.finish()
+        got = enc.scan(n)
+    else:
+        n_img = int(rng.integers(2, 6))
+        others = [content(w, h, int(rng.integers(5)), stride) for _ in range(n_img - 1)]
+        k = int(rng.integers(n_img))
+        imgs = others[:k] + [rows] + others[k:]
+        dev = [torch.from_numpy(r).cuda() for r in imgs]
+        torch.cuda.synchronize()
+        enc.encode_batch_device_async([t.data_ptr() for t in dev], w, h, stride, bottom_up)
+        enc.finish()
+        got = enc.batch_scan(k)
+    if not np.array_equal(got, want):
+        print("MISMATCH", dict(ratio=ratio, algo=algo, w=w, h=h, stride=stride, bottom_up=bottom_up, kind=kind, mode=mode),
+              len(got), len(want), flush=True)
+        sys.exit(1)
+    done += 1
+    fused += int(enc.fused_coding())
+    if it % 25 == 24:
+        print("%d cases ok (%d through the fused coding kernel), %.0f s" % (done, fused, time.time() - t0), flush=True)
+print("fuzz ok: %d cases, %d through the fused coding kernel" % (done, fused))
