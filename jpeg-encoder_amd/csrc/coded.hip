@@ -81,12 +81,20 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
     const bool has_halo = tile > 0;
     const int hmx = mcu0 ? mcu0 - 1 : g.mcux - 1, hmy = mcu0 ? tile_y : tile_y - 1;
 
-    for (int i = tid; i < LUT_WORDS; i += THREADS) sLut[i] = (&HUFF_DEV.e[0][0])[i];
+    // The Huffman table travels to LDS through registers: its loads are issued here, ahead of the pixel loads,
+    // and stored after the conversion, so that nothing waits for them.
+    constexpr int LUT_ROUNDS = (LUT_WORDS + THREADS - 1) / THREADS;
+    uint32_t lut_words[LUT_ROUNDS];
+#pragma unroll
+    for (int k = 0; k < LUT_ROUNDS; k++) lut_words[k] = (&HUFF_DEV.e[0][0])[min(tid + k * THREADS, LUT_WORDS - 1)];
     for (int i = tid; i < WIN_WORDS + 2; i += THREADS) sWin[i] = 0;
 
     HaloRegs<VS> halo;
     halo_load<HS, VS>(src, g, hmx * 8 * HS, hmy * 8 * VS, has_halo ? tid - 64 * C::SPARE_WAVE : -1, halo);
     tile_convert<HS, VS>(src, g, x0, y0, mcus, sY, sCb, sCr, tid);
+#pragma unroll
+    for (int k = 0; k < LUT_ROUNDS; k++)
+        if (tid + k * THREADS < LUT_WORDS) sLut[tid + k * THREADS] = lut_words[k];
     __syncthreads();
     tile_transform<HS, VS, ALGO>(lds, mcus, tid, [&] {
         if (!has_halo) return;
