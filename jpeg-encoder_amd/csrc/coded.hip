@@ -60,18 +60,10 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
     uint8_t *sCr = sCb + 8 * C::CW;
     const Geom &g = a.g;
 
-    const int tiles_x = (g.mcux + C::MCUS - 1) / C::MCUS;
-    int tile = blockIdx.x;
-    int img = 0;
-    const uint8_t *src = a.src;
-    if (a.srcs) {
-        const int per_image = tiles_x * g.mcuy;
-        img = tile / per_image;
-        tile -= img * per_image;
-        src = a.srcs[img];
-    }
-    const int tile_x = tile % tiles_x;
-    const int tile_y = tile / tiles_x;
+    // grid: x = tile column, y = MCU row, z = image of a batch (no divisions to find the tile)
+    const int tile_x = blockIdx.x, tile_y = blockIdx.y, img = blockIdx.z;
+    const int tile = tile_y * (int)gridDim.x + tile_x;       // number of the tile in the scan of its image
+    const uint8_t *src = a.srcs ? a.srcs[img] : a.src;
     const int mcu0 = tile_x * C::MCUS;                        // first MCU column of the tile
     const int mcus = min(C::MCUS, g.mcux - mcu0);             // MCUs really present
     const int x0 = mcu0 * 8 * HS;
@@ -233,7 +225,8 @@ static hipError_t launch_coded_hv(const CodedArgs &a, int algo, int nimg, hipStr
     const long long tiles = (long long)tiles_x * a.g.mcuy;
     if (tiles <= 0 || tiles * nimg > 0x7fffffffLL || tiles > a.cstride || a.slot_words != coded_slot_words(a.g))
         return hipErrorInvalidValue;
-    const dim3 grid((unsigned)(tiles * nimg)), block(THREADS);
+    if (a.g.mcuy > 65535 || nimg > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)tiles_x, (unsigned)a.g.mcuy, (unsigned)nimg), block(THREADS);
     switch (algo) {
         case ALGO_REAL: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, a); break;
         case ALGO_BIN: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, a); break;
