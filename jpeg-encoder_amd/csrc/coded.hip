@@ -79,7 +79,6 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
     uint32_t lut_words[LUT_ROUNDS];
 #pragma unroll
     for (int k = 0; k < LUT_ROUNDS; k++) lut_words[k] = (&HUFF_DEV.e[0][0])[min(tid + k * THREADS, LUT_WORDS - 1)];
-    for (int i = tid; i < WIN_WORDS + 2; i += THREADS) sWin[i] = 0;
 
     HaloRegs<VS> halo;
     halo_load<HS, VS>(src, g, hmx * 8 * HS, hmy * 8 * VS, has_halo ? tid - 64 * C::SPARE_WAVE : -1, halo);
@@ -87,6 +86,7 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
 #pragma unroll
     for (int k = 0; k < LUT_ROUNDS; k++)
         if (tid + k * THREADS < LUT_WORDS) sLut[tid + k * THREADS] = lut_words[k];
+    for (int i = tid; i < WIN_WORDS + 2; i += THREADS) sWin[i] = 0;   // (after the loads, like the table)
     __syncthreads();
     tile_transform<HS, VS, ALGO>(lds, mcus, tid, [&] {
         if (!has_halo) return;
