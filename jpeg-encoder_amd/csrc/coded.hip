@@ -80,8 +80,6 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
 #pragma unroll
     for (int k = 0; k < LUT_ROUNDS; k++) lut_words[k] = (&HUFF_DEV.e[0][0])[min(tid + k * THREADS, LUT_WORDS - 1)];
 
-    HaloRegs<VS> halo;
-    halo_load<HS, VS>(src, g, hmx * 8 * HS, hmy * 8 * VS, has_halo ? tid - 64 * C::SPARE_WAVE : -1, halo);
     tile_convert<HS, VS>(src, g, x0, y0, mcus, sY, sCb, sCr, tid);
 #pragma unroll
     for (int k = 0; k < LUT_ROUNDS; k++)
@@ -90,6 +88,8 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
     __syncthreads();
     tile_transform<HS, VS, ALGO>(lds, mcus, tid, [&] {
         if (!has_halo) return;
+        HaloRegs<VS> halo;
+        halo_load<HS, VS>(src, g, hmx * 8 * HS, hmy * 8 * VS, lane, halo);
         halo_convert<HS, VS>(src, g, hmx * 8 * HS, hmy * 8 * VS, sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, halo);
         __builtin_amdgcn_wave_barrier();   // (the LDS accesses of one wave execute in order)
         halo_dc<HS, VS, ALGO>(sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, sHaloDc);
