@@ -709,9 +709,10 @@ extern "C" int jpg_front_host(jpg_ctx *c, const uint8_t *pixels, int32_t W, int3
 // A whole encode of the staged rows (or of the batch srcs[0..n-1]): coding on `stream`, stuffing on
 // stream_b, into the slot the previous encodes do not use.  The fused coding kernel where the
 // geometry allows it, else the front kernel and the entropy kernel.
+// srcs: host array of the batch's device pointers.
 static int queue_encode(jpg_ctx *c, const uint8_t *const *srcs = nullptr, int n = 1) {
     c->cur = (c->cur + 1) % jpg_ctx::NSLOT;
-    if (!c->two_kernels && coded_supported(c->g)) {
+    if (!c->two_kernels && coded_supported(c->g) && n <= 64) {
         if (int e = prepare_slot(c, true)) return e;
         if (int e = launch_timed(c, n, [&](hipEvent_t e0, hipEvent_t e1) {
                 return launch_coded(c->g, c->algo, c->d_src, srcs, n, ZERO_PRED, S(c).eb, c->stream, e0, e1);
@@ -719,7 +720,14 @@ static int queue_encode(jpg_ctx *c, const uint8_t *const *srcs = nullptr, int n 
             return e;
         c->coef_valid = false;
     } else {
-        if (int e = queue_front(c, srcs, n)) return e;
+        const uint8_t *const *d_srcs = nullptr;
+        if (srcs) {   // the front kernel reads the pointers from memory
+            jpg_ctx::Slot &sl = S(c);
+            if (int e = grow(c, sl.d_srcs, sl.cap_srcs, (size_t)n)) return e;
+            HIP_TRY(c, hipMemcpyAsync(sl.d_srcs, srcs, (size_t)n * sizeof(uint8_t *), hipMemcpyHostToDevice, c->stream));
+            d_srcs = sl.d_srcs;
+        }
+        if (int e = queue_front(c, d_srcs, n)) return e;
         if (int e = queue_entropy(c, nullptr)) return e;
     }
     c->stage = ST_COEF;
@@ -757,10 +765,7 @@ extern "C" int jpg_encode_batch_device_async(jpg_ctx *c, const uint8_t *const *d
         if (!dev_pixels[i] || (reinterpret_cast<uintptr_t>(dev_pixels[i]) & 3)) return JPG_ERR_BAD_ARG;
     c->nimg = n;
     c->d_src = dev_pixels[0];
-    jpg_ctx::Slot &next = c->slot[(c->cur + 1) % jpg_ctx::NSLOT];   // the slot queue_encode is about to use
-    if (int e = grow(c, next.d_srcs, next.cap_srcs, (size_t)n)) return e;
-    HIP_TRY(c, hipMemcpyAsync(next.d_srcs, dev_pixels, (size_t)n * sizeof(uint8_t *), hipMemcpyHostToDevice, c->stream));
-    return queue_encode(c, next.d_srcs, n);
+    return queue_encode(c, dev_pixels, n);
 }
 
 extern "C" int jpg_batch_result(jpg_ctx *c, int32_t i, uint64_t *nbits, size_t *stuffed_len, const uint8_t **scan_dev) {

@@ -30,9 +30,12 @@ namespace jpg {
 // 2 % faster on photo-like content, 23 % slower on noise, whose tiles then take 8 passes instead of 2.)
 constexpr int WIN_WORDS = 2048;
 
+constexpr int MAX_LAUNCH_IMAGES = 64;   // images of one launch: their pixel pointers travel in the argument block
+
 struct CodedArgs {
-    const uint8_t *src;
-    const uint8_t *const *srcs;   // a batch: pixel array of each image (else null)
+    // Pixel array of each image of the launch.  In the argument block rather than in memory: the pointer is
+    // then one scalar load away at the start of the kernel instead of two dependent ones.
+    const uint8_t *src[MAX_LAUNCH_IMAGES];
     Geom g;
     int16_t pred[3];              // DC predictors the first MCU of every image starts from
     uint32_t epoch;               // tags errors (see raise_error)
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
     // grid: x = tile column, y = MCU row, z = image of a batch (no divisions to find the tile)
     const int tile_x = blockIdx.x, tile_y = blockIdx.y, img = blockIdx.z;
     const int tile = tile_y * (int)gridDim.x + tile_x;       // number of the tile in the scan of its image
-    const uint8_t *src = a.srcs ? a.srcs[img] : a.src;
+    const uint8_t *src = a.src[img];
     const int mcu0 = tile_x * C::MCUS;                        // first MCU column of the tile
     const int mcus = min(C::MCUS, g.mcux - mcu0);             // MCUs really present
     const int x0 = mcu0 * 8 * HS;
@@ -248,14 +251,18 @@ long long coded_tiles(const Geom &g) { return (long long)((g.mcux + tile_mcus(g)
 
 int coded_slot_words(const Geom &g) { return tile_mcus(g) * g.nb * SLOT_WORDS_PER_BLOCK; }
 
+// srcs: host array of the nimg device pointers of a batch, or null for the single image `src`
 hipError_t launch_coded(const Geom &g, int algo, const uint8_t *src, const uint8_t *const *srcs, int nimg,
                         const int16_t pred[3], const EntropyBufs &b, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     // rows are read as dwords (the caller checks the pointers of a batch)
-    if ((!srcs && (reinterpret_cast<uintptr_t>(src) & 3)) || (g.stride & 3) || nimg < 1 || !coded_supported(g))
-        return hipErrorInvalidValue;
     if (!srcs) nimg = 1;
+    if ((g.stride & 3) || nimg < 1 || nimg > MAX_LAUNCH_IMAGES || !coded_supported(g)) return hipErrorInvalidValue;
     if (nimg != (b.nimg > 0 ? b.nimg : 1) || b.nchunks != coded_tiles(g)) return hipErrorInvalidValue;
-    CodedArgs a{src, srcs, g, {pred[0], pred[1], pred[2]}, b.epoch, b.cstride, b.slot_words, b.clen, b.sparse, b.status};
+    CodedArgs a{{}, g, {pred[0], pred[1], pred[2]}, b.epoch, b.cstride, b.slot_words, b.clen, b.sparse, b.status};
+    for (int i = 0; i < nimg; i++) {
+        a.src[i] = srcs ? srcs[i] : src;
+        if (!a.src[i] || (reinterpret_cast<uintptr_t>(a.src[i]) & 3)) return hipErrorInvalidValue;   // rows are read as dwords
+    }
     if (g.h == 2 && g.v == 2) return launch_coded_hv<2, 2>(a, algo, nimg, s, e0, e1);
     if (g.h == 2 && g.v == 1) return launch_coded_hv<2, 1>(a, algo, nimg, s, e0, e1);
     if (g.h == 1 && g.v == 1) return launch_coded_hv<1, 1>(a, algo, nimg, s, e0, e1);
