@@ -246,8 +246,8 @@ def main():
             roof["isolated_kernel_ms_per_image"] = round(kms, 5)
         if fused:
             # HBM is the nearer of the two rooflines the kernel could be priced against, but neither binds it
-            roof["note"] = ("bound by vector-ALU instruction issue, not by HBM: 29.3 M wavefront VALU instructions per "
-                            "image, SQ_ACTIVE_INST_VALU*4/SIMDs/cycles = 1.1 (profiles/r01_coded_pmc.json); the kernel "
+            roof["note"] = ("bound by vector-ALU instruction issue, not by HBM: 28.9 M wavefront VALU instructions per "
+                            "image, SQ_ACTIVE_INST_VALU*4/SIMDs/cycles = 1.15 (profiles/r01_coded_pmc.json); the kernel "
                             "reads each pixel once and writes only the coded bits")
         if fused:
             # for comparison, outside the timed region: the front kernel alone (coefficients to memory,
