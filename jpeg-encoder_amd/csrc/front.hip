@@ -28,17 +28,12 @@ __global__ __launch_bounds__(THREADS) void k_front(const uint8_t *__restrict__ s
     uint8_t *sCb = lds + C::TILE_H * C::TW;
     uint8_t *sCr = sCb + 8 * C::CW;
 
-    const int tiles_x = (g.mcux + C::MCUS - 1) / C::MCUS;
-    int tile = blockIdx.x;
+    // grid: x = tile column, y = MCU row, z = image of a batch (no divisions to find the tile)
+    const int tile_x = blockIdx.x, tile_y = blockIdx.y;
     if (srcs) {
-        const int per_image = tiles_x * g.mcuy;
-        const int img = tile / per_image;
-        tile -= img * per_image;
-        src = srcs[img];
-        coef += (size_t)img * (size_t)g.nblocks * 64;
+        src = srcs[blockIdx.z];
+        coef += (size_t)blockIdx.z * (size_t)g.nblocks * 64;
     }
-    const int tile_x = tile % tiles_x;
-    const int tile_y = tile / tiles_x;
     const int mcu0 = tile_x * C::MCUS;                        // first MCU column of the tile
     const int mcus = min(C::MCUS, g.mcux - mcu0);             // MCUs really present
     const int x0 = mcu0 * 8 * HS;
@@ -65,8 +60,8 @@ static hipError_t launch_front_hv(const Geom &g, int algo, const uint8_t *src, c
     using C = TileCfg<HS, VS>;
     const int tiles_x = (g.mcux + C::MCUS - 1) / C::MCUS;
     const long long tiles = (long long)tiles_x * g.mcuy * nimg;
-    if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)tiles), block(THREADS);
+    if (tiles <= 0 || tiles > 0x7fffffffLL || g.mcuy > 65535 || nimg > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)tiles_x, (unsigned)g.mcuy, (unsigned)nimg), block(THREADS);
     switch (algo) {
         case ALGO_REAL: hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, src, srcs, g, coef); break;
         case ALGO_BIN: hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, src, srcs, g, coef); break;
