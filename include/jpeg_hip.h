@@ -38,7 +38,8 @@ typedef enum jpg_status {
                                       reference's chroma plane is skewed there (src/jpeg/sampling.rs:56-101
                                       pushes (Wp/h)*(Hp/v) samples into a plane declared Wc x Hc) */
     JPG_ERR_NOMEM = -10,
-    JPG_ERR_CAPACITY = -11      /* caller buffer too small */
+    JPG_ERR_CAPACITY = -11,     /* caller buffer too small */
+    JPG_ERR_TOO_LARGE = -12     /* more blocks than the call's kernels index (see the call) */
 } jpg_status;
 
 /* src/jpeg/dct_quant.rs:8-12.  JPG_DCT_REAL is the separable f32 transform

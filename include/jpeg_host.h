@@ -15,7 +15,9 @@ extern "C" {
 
 #define JPH_OK 0
 #define JPH_ERR_OPEN -1     /* "Could not open bitmap image file!\n"  src/bmp/bmp_image.rs:26 */
-#define JPH_ERR_FORMAT -2   /* width/height not positive */
+#define JPH_ERR_FORMAT -2   /* width or height not positive (a negative height is a top-down file), bits per pixel
+                               (u16 at offset 28) != 24, or compression (u32 at offset 30) != 0: the checks the
+                               reference leaves as TODOs (src/bmp/bmp_image.rs:22-24) */
 #define JPH_ERR_IO -3
 #define JPH_ERR_NOMEM -4
 #define JPH_ERR_ARG -5
@@ -29,7 +31,8 @@ typedef struct jph_bmp {
 
 /* BmpImage::new + load_pixels (src/bmp/bmp_image.rs:21-90) with one buffered
  * read instead of one syscall per pixel.  Like the reference, only the three
- * header fields above are interpreted.  If the file ends early the missing
+ * header fields above are interpreted; unlike it, files that are not uncompressed
+ * 24-bit bottom-up bitmaps are refused (JPH_ERR_FORMAT) instead of misread.  If the file ends early the missing
  * pixels repeat the last 3-byte buffer, as the reference's ignored short
  * reads do.  Release with jph_bmp_free. */
 int jph_bmp_read(const char *path, jph_bmp *out);

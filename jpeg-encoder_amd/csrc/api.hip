@@ -45,6 +45,8 @@ struct jpg_ctx {
         hipEvent_t s_done = nullptr;    // stuffing kernel finished (recorded on the stream it ran on)
         bool busy = false;              // s_done has been recorded at least once
         bool dense_valid = false;       // eb.bits holds the dense stream of the last entropy launch
+        size_t nblocks = 0;             // blocks of the image the slot's chunks were coded from (sizes the dense stream)
+        size_t cap_ticket = 0;
         uint64_t nbits = 0;
         size_t scan_len = 0;
     } slot[NSLOT];
@@ -95,10 +97,11 @@ extern "C" const char *jpg_strerror(int st) {
         case JPG_ERR_HIP: return "HIP runtime error";
         case JPG_ERR_STATE: return "stage called out of order";
         case JPG_ERR_UNSUPPORTED_DIMS:
-            return "unsupported dimensions: the reference skews the chroma plane when width %% 16 == 1 (h=2) or "
-                   "height %% 16 == 1 (v=2)";
+            return "unsupported dimensions: the reference skews the chroma plane when width % 16 == 1 (h=2) or "
+                   "height % 16 == 1 (v=2)";
         case JPG_ERR_NOMEM: return "out of memory";
         case JPG_ERR_CAPACITY: return "output buffer too small";
+        case JPG_ERR_TOO_LARGE: return "image too large for this path";
     }
     return "unknown status";
 }
@@ -107,8 +110,24 @@ extern "C" int jpg_last_hip_error(const jpg_ctx *ctx) { return ctx ? ctx->last_h
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-static int use_device(jpg_ctx *c) {
-    HIP_TRY(c, hipSetDevice(c->device));
+// Entry points make the context's device current and put the caller's device back when they return.
+struct DeviceGuard {
+    int prev = -1;
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+static int use_device(jpg_ctx *c, DeviceGuard &g) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) {
+        (void)hipGetLastError();
+        cur = -1;
+    }
+    if (cur != c->device) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        g.prev = cur;
+    }
     return JPG_OK;
 }
 
@@ -157,6 +176,8 @@ extern "C" int jpg_create(jpg_ctx **out, int device, int dct_algo, int ra, int r
     jpg_ctx *c = new (std::nothrow) jpg_ctx();
     if (!c) return JPG_ERR_NOMEM;
     c->device = device; c->algo = dct_algo; c->h = h; c->v = v;
+    DeviceGuard dg;
+    if (hipGetDevice(&dg.prev) != hipSuccess) { (void)hipGetLastError(); dg.prev = -1; }
     // (stream priorities were tried for the two streams and made no difference)
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -184,6 +205,8 @@ extern "C" int jpg_create(jpg_ctx **out, int device, int dct_algo, int ra, int r
 
 extern "C" void jpg_destroy(jpg_ctx *c) {
     if (!c) return;
+    DeviceGuard dg;
+    if (hipGetDevice(&dg.prev) != hipSuccess) { (void)hipGetLastError(); dg.prev = -1; }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
@@ -193,7 +216,7 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
         if (p) (void)hipFree(p);
     for (jpg_ctx::Slot &sl : c->slot) {
         void *sdev[] = {sl.d_srcs, sl.eb.clen, sl.eb.sparse, sl.eb.status, sl.eb.bits, sl.eb.sagg, sl.eb.sgrp, sl.eb.shyp,
-                        sl.eb.scan, sl.eb.trace};
+                        sl.eb.sticket, sl.eb.scan, sl.eb.trace};
         for (void *p : sdev)
             if (p) (void)hipFree(p);
         if (sl.h_status) (void)hipHostFree(sl.h_status);
@@ -216,7 +239,8 @@ extern "C" void *jpg_stream(jpg_ctx *c) { return c ? (void *)c->stream : nullptr
 
 extern "C" int jpg_sync(jpg_ctx *c) {
     if (!c) return JPG_ERR_BAD_ARG;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     return sync_all(c);
 }
 
@@ -268,7 +292,7 @@ static int ensure_entropy(jpg_ctx *c, bool coded) {
     const size_t nblk = (size_t)c->g.nblocks;
     const size_t nchunks = coded ? (size_t)coded_tiles(c->g) : (nblk + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
     const size_t slot_words = coded ? (size_t)coded_slot_words(c->g) : (size_t)CHUNK_STRIDE_WORDS;
-    if ((nchunks + 63) / 64 > (size_t)MAX_GROUPS) return JPG_ERR_CAPACITY;
+    if ((nchunks + 63) / 64 > (size_t)MAX_GROUPS) return JPG_ERR_TOO_LARGE;
     const size_t cstride = (nchunks + 63) / 64 * 64;
     const size_t bits_bytes = worst_bits_bytes(nblk);
     const size_t scan_stride = (2 * bits_bytes + 16 + 255) / 256 * 256;
@@ -277,6 +301,7 @@ static int ensure_entropy(jpg_ctx *c, bool coded) {
     sl.eb.nchunks = (long long)nchunks;
     sl.eb.cstride = (long long)cstride;
     sl.eb.slot_words = (int)slot_words;
+    sl.nblocks = nblk;
     int e;
     if ((e = grow(c, sl.eb.clen, sl.cap_clen, nimg * cstride))) return e;
     if ((e = grow(c, sl.eb.sparse, sl.cap_sparse, nimg * cstride * slot_words))) return e;
@@ -294,6 +319,10 @@ static int ensure_entropy(jpg_ctx *c, bool coded) {
         sl.cap_status = nimg;
         sl.eb.epoch = 0;
     }
+    if (2 * nimg > sl.cap_ticket) {
+        if ((e = grow(c, sl.eb.sticket, sl.cap_ticket, 2 * nimg))) return e;
+        HIP_TRY(c, hipMemset(sl.eb.sticket, 0, sl.cap_ticket * sizeof(uint32_t)));   // the kernel leaves them at 0
+    }
     // the hand-off words are laid out per image with the stride nseg: a change of either relocates them
     if (nseg != sl.eb.nseg_cap || nimg * nseg > sl.cap_sagg) {
         if ((e = grow(c, sl.eb.sagg, sl.cap_sagg, nimg * nseg))) return e;
@@ -308,7 +337,8 @@ static int ensure_entropy(jpg_ctx *c, bool coded) {
 // the dense copy of the stream is only kept for the staged calls
 static int ensure_dense(jpg_ctx *c) {
     jpg_ctx::Slot &sl = V(c);
-    const size_t need = worst_bits_bytes((size_t)c->g.nblocks);
+    // sized for the image whose chunks the viewed slot holds, which need not be the one queued last
+    const size_t need = worst_bits_bytes(sl.nblocks);
     if (sl.eb.bits && sl.eb.bits_cap >= need) return JPG_OK;
     if (int e = regrow(c, sl.eb.bits, need / 4)) return e;
     sl.eb.bits_cap = need;
@@ -383,7 +413,8 @@ static int stage_input(jpg_ctx *c, const uint8_t *pixels, bool on_host) {
 static int load_common(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride, int bottom_up,
                        bool on_host) {
     if (!c || !pixels) return JPG_ERR_BAD_ARG;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
     if (int e = stage_input(c, pixels, on_host)) return e;
     const size_t n = (size_t)c->g.Wp * c->g.Hp;
@@ -412,7 +443,8 @@ extern "C" int jpg_load_bgr_device(jpg_ctx *c, const uint8_t *pixels, int32_t W,
 extern "C" int jpg_downsample(jpg_ctx *c) {
     if (!c) return JPG_ERR_BAD_ARG;
     if (c->stage != ST_PLANES) return JPG_ERR_STATE;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (c->h != 1 || c->v != 1) {
         const size_t n = (size_t)c->g.Wc * c->g.Hc;
         if (n > c->down_cap || !c->d_down[0]) {
@@ -432,7 +464,8 @@ extern "C" int jpg_downsample(jpg_ctx *c) {
 extern "C" int jpg_dct_quant(jpg_ctx *c) {
     if (!c) return JPG_ERR_BAD_ARG;
     if (c->stage != ST_DOWN) return JPG_ERR_STATE;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (int e = ensure_coef(c)) return e;
     const bool sub = c->h != 1 || c->v != 1;
     HIP_TRY(c, launch_dct_planes(c->g, c->algo, c->d_plane[0], sub ? c->d_down[0] : c->d_plane[1],
@@ -490,7 +523,8 @@ static int queue_front(jpg_ctx *c, const uint8_t *const *srcs = nullptr, int n =
 
 extern "C" int jpg_set_timing(jpg_ctx *c, int every) {
     if (!c) return JPG_ERR_BAD_ARG;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->t_pending = 0;
     c->t_total_ms = 0.0;
@@ -503,7 +537,8 @@ extern "C" int jpg_set_timing(jpg_ctx *c, int every) {
 
 extern "C" int jpg_front_time(jpg_ctx *c, double *total_ms, uint64_t *launches, uint64_t *images) {
     if (!c) return JPG_ERR_BAD_ARG;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (int e = harvest_timing(c)) return e;
     if (total_ms) *total_ms = c->t_total_ms;
@@ -600,7 +635,8 @@ static bool code_from_rows(const jpg_ctx *c) {
 static int entropy_common(jpg_ctx *c, const int16_t *pred, uint64_t *nbits) {
     if (!c) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_COEF) return JPG_ERR_STATE;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     c->npend = 0;
     if (code_from_rows(c)) {
         // no coefficients were asked for so far: one kernel from the rows to the coded tiles
@@ -628,7 +664,8 @@ extern "C" int jpg_entropy_stripe(jpg_ctx *c, const int16_t pred[3], uint64_t *n
 extern "C" int jpg_stream_tail(jpg_ctx *c, uint32_t *last32) {
     if (!c || !last32) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_BITS || c->npend) return JPG_ERR_STATE;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (int e = make_dense(c)) return e;
     const jpg_ctx::Slot &sl = V(c);
     const uint64_t nbytes = (sl.nbits + 7) >> 3;
@@ -650,7 +687,8 @@ extern "C" int jpg_stream_tail(jpg_ctx *c, uint32_t *last32) {
 extern "C" int jpg_last_dc(jpg_ctx *c, int16_t dc[3]) {
     if (!c || !dc) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_COEF) return JPG_ERR_STATE;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (code_from_rows(c)) {
         HIP_TRY(c, launch_last_dc_pixels(c->g, c->algo, c->d_src, c->d_dc, c->stream));
     } else {
@@ -666,7 +704,8 @@ extern "C" int jpg_last_dc(jpg_ctx *c, int16_t dc[3]) {
 extern "C" int jpg_stitch(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, int is_last, size_t *len, uint8_t *tail) {
     if (!c) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_BITS || c->npend) return JPG_ERR_STATE;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (int e = queue_stuff(c, bit_offset, head_bits, is_last, c->stream)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     jpg_ctx::Slot &sl = S(c);
@@ -683,7 +722,8 @@ extern "C" int jpg_stuff(jpg_ctx *c, size_t *len) { return jpg_stitch(c, 0, 0, 1
 extern "C" int jpg_front_device(jpg_ctx *c, const uint8_t *dev_pixels, int32_t W, int32_t H, uint32_t stride,
                                 int bottom_up) {
     if (!c || !dev_pixels) return JPG_ERR_BAD_ARG;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
     if (int e = stage_input(c, dev_pixels, false)) return e;
     if (int e = queue_front(c)) return e;
@@ -693,7 +733,8 @@ extern "C" int jpg_front_device(jpg_ctx *c, const uint8_t *dev_pixels, int32_t W
 
 extern "C" int jpg_front_host(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride, int bottom_up) {
     if (!c || !pixels) return JPG_ERR_BAD_ARG;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
     if (int e = stage_input(c, pixels, true)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // caller may reuse `pixels`
@@ -743,7 +784,8 @@ static int queue_encode(jpg_ctx *c, const uint8_t *const *srcs = nullptr, int n 
 extern "C" int jpg_encode_device_async(jpg_ctx *c, const uint8_t *dev_pixels, int32_t W, int32_t H, uint32_t stride,
                                        int bottom_up) {
     if (!c || !dev_pixels) return JPG_ERR_BAD_ARG;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
     if (int e = stage_input(c, dev_pixels, false)) return e;
     return queue_encode(c);
@@ -756,9 +798,10 @@ extern "C" int jpg_max_batch(void) { return 64; }
 extern "C" int jpg_encode_batch_device_async(jpg_ctx *c, const uint8_t *const *dev_pixels, int32_t n, int32_t W, int32_t H,
                                              uint32_t stride, int bottom_up) {
     if (!c || !dev_pixels || n < 1 || n > jpg_max_batch()) return JPG_ERR_BAD_ARG;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
-    if ((int64_t)c->g.nblocks * n >= (1LL << 31)) return JPG_ERR_CAPACITY;
+    if ((int64_t)c->g.nblocks * n >= (1LL << 31)) return JPG_ERR_TOO_LARGE;
     // a batch is read in place: rows must be dword-aligned (single images are re-pitched instead)
     if (stride & 3) return JPG_ERR_BAD_ARG;
     for (int i = 0; i < n; i++)
@@ -785,7 +828,8 @@ extern "C" int jpg_get_batch_scan(jpg_ctx *c, int32_t i, uint8_t *out, size_t ca
     const uint8_t *src = nullptr;
     if (int e = jpg_batch_result(c, i, nullptr, &len, &src)) return e;
     if (cap < len) return JPG_ERR_CAPACITY;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     HIP_TRY(c, hipMemcpyAsync(out, src, len, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return JPG_OK;
@@ -823,7 +867,8 @@ static int report(jpg_ctx *c, int k, uint64_t *nbits, size_t *stuffed_len) {
 extern "C" int jpg_finish(jpg_ctx *c, uint64_t *nbits, size_t *stuffed_len) {
     if (!c) return JPG_ERR_BAD_ARG;
     if (!c->npend) return JPG_ERR_STATE;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (int e = sync_all(c)) return e;
     c->npend = 0;
 #ifdef JPG_TRACE
@@ -835,7 +880,8 @@ extern "C" int jpg_finish(jpg_ctx *c, uint64_t *nbits, size_t *stuffed_len) {
 extern "C" int jpg_finish_next(jpg_ctx *c, uint64_t *nbits, size_t *stuffed_len) {
     if (!c) return JPG_ERR_BAD_ARG;
     if (!c->npend) return JPG_ERR_STATE;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     const int k = c->fifo[0];
     HIP_TRY(c, hipEventSynchronize(c->slot[k].s_done));
     for (int j = 1; j < c->npend; j++) c->fifo[j - 1] = c->fifo[j];
@@ -847,7 +893,8 @@ extern "C" int jpg_encode_scan(jpg_ctx *c, const uint8_t *pixels, int32_t W, int
                                uint8_t **stuffed, size_t *len) {
     if (!c || !pixels || !stuffed || !len) return JPG_ERR_BAD_ARG;
     *stuffed = nullptr; *len = 0;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
     if (int e = stage_input(c, pixels, true)) return e;
     if (int e = queue_encode(c)) return e;
@@ -879,17 +926,19 @@ extern "C" void jpg_free(void *p) {
 
 extern "C" const uint8_t *jpg_bits_device(jpg_ctx *c) {
     if (!c || c->stage < ST_BITS || c->npend) return nullptr;
-    if (use_device(c) || make_dense(c)) return nullptr;
+    DeviceGuard dg;
+    if (use_device(c, dg) || make_dense(c)) return nullptr;
     return reinterpret_cast<const uint8_t *>(V(c).eb.bits);
 }
 extern "C" const uint8_t *jpg_scan_device(jpg_ctx *c) { return c && c->stage >= ST_SCAN ? V(c).eb.scan : nullptr; }
 
 extern "C" int jpg_get_bits(jpg_ctx *c, uint8_t *out, size_t cap) {
     if (!c || !out) return JPG_ERR_BAD_ARG;
-    if (c->stage < ST_BITS) return JPG_ERR_STATE;
+    if (c->stage < ST_BITS || c->npend) return JPG_ERR_STATE;   // (queued encodes still write the slots)
     const size_t n = (size_t)((V(c).nbits + 7) >> 3);
     if (cap < n) return JPG_ERR_CAPACITY;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (int e = make_dense(c)) return e;
     HIP_TRY(c, hipMemcpyAsync(out, V(c).eb.bits, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -901,7 +950,8 @@ extern "C" int jpg_get_scan(jpg_ctx *c, uint8_t *out, size_t cap) {
     if (c->stage < ST_SCAN) return JPG_ERR_STATE;
     const jpg_ctx::Slot &sl = V(c);
     if (cap < sl.scan_len) return JPG_ERR_CAPACITY;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     HIP_TRY(c, hipMemcpyAsync(out, sl.eb.scan, sl.scan_len, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return JPG_OK;
@@ -931,7 +981,8 @@ extern "C" int jpg_get_plane(jpg_ctx *c, int comp, uint8_t *out, size_t cap) {
     if (int e = jpg_plane_dims(c, comp, &w, &h)) return e;
     const size_t n = (size_t)w * h;
     if (cap < n) return JPG_ERR_CAPACITY;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     const bool down = comp > 0 && c->down_done && (c->h != 1 || c->v != 1);
     const uint8_t *src = down ? c->d_down[comp - 1] : c->d_plane[comp];
     HIP_TRY(c, hipMemcpyAsync(out, src, n, hipMemcpyDeviceToHost, c->stream));
@@ -944,7 +995,8 @@ extern "C" int jpg_get_coeffs(jpg_ctx *c, int comp, int16_t *out, size_t cap) {
     if (c->stage < ST_COEF) return JPG_ERR_STATE;
     const size_t n = comp ? (size_t)c->g.Wc * c->g.Hc : (size_t)c->g.Wp * c->g.Hp;
     if (cap < n * sizeof(int16_t)) return JPG_ERR_CAPACITY;
-    if (int e = use_device(c)) return e;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
     if (int e = need_coef(c)) return e;
     if (int e = grow(c, c->d_tmp16, c->tmp16_cap, n)) return e;
     HIP_TRY(c, launch_unscan(c->g, c->d_coef, comp, c->d_tmp16, c->stream));

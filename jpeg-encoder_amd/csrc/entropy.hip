@@ -20,6 +20,8 @@
 // their place, straight from the chunk slots.  Stuffing then inserts 0x00 after
 // every 0xFF; the output offset of a segment comes from three levels of running
 // sums of the 0xFF counts, published by the segments before it.
+#include <atomic>
+
 #include "coding.hpp"
 
 namespace jpg {
@@ -313,6 +315,7 @@ struct StreamArgs {
     uint32_t head;           // bits OR-ed into the first byte (top `shift` bits)
     int is_last;             // keep the trailing partial byte
     uint64_t *agg, *grp, *hyp;  // three-level sums of 0xFF counts per segment
+    uint32_t *ticket;        // [nimg][2] next segment to hand out, workgroups that have left (both 0 between launches)
     uint32_t epoch;          // generation of those words
     uint32_t err_epoch;      // epoch errors are tagged with (that of the entropy launch)
     uint8_t *out;            // stuffed bytes, or the dense stream for k_stream<false>
@@ -388,6 +391,7 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         a.agg += img * a.agg_stride;
         a.grp += img * a.grp_stride;
         a.hyp += img * a.hyp_stride;
+        if (STUFF) a.ticket += 2 * img;
         a.status += img;
         if (a.host_status) a.host_status += img;
     }
@@ -400,7 +404,16 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     __shared__ uint32_t sD[DENSE_WORDS];   // the segment's bits in place
     __shared__ uint32_t s[ST_WAVES];
     __shared__ uint64_t sBefore;
+    __shared__ uint32_t sSeg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Stuffing: segments are handed out by a ticket counter, lowest first, so every segment with a lower
+    // number than one a workgroup holds is held by a workgroup that is running (or has finished): the waits
+    // below make progress however few workgroups are resident and whatever else runs on the device.  The
+    // ticket of the following round is fetched while the current segment is worked on, by a thread of the
+    // last wave, which loads nothing else in the first phases of a round (a wave's loads return in order).
+    const bool ticketer = tid == ST_THREADS - 1;
+    uint32_t ticket = 0;
+    if (STUFF && ticketer) ticket = atomicAdd(&a.ticket[0], 1u);
 #ifdef JPG_TRACE
     unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool stamped = false;
@@ -459,7 +472,14 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const uint64_t nloop = nseg ? nseg : 1;          // the tail of an empty stripe still has to be reported
     const Sums sums{a.agg, a.grp, a.hyp, a.epoch, (long long)nseg};
 
-    for (uint64_t seg = wg; seg < nloop; seg += nwg) {
+    uint64_t seg = wg;
+    if (STUFF) {
+        if (ticketer) sSeg = ticket;
+        lds_barrier();
+        seg = sSeg;
+    }
+    while (seg < nloop) {
+        if (STUFF && ticketer) ticket = atomicAdd(&a.ticket[0], 1u);   // used at the end of this round
         // ---- offsets of the chunks under this segment (first TABLE threads)
         const long long P0 = (long long)seg * SEG_BITS - (long long)a.shift;   // stream position of the segment's first bit
         const uint64_t p0 = P0 > 0 ? (uint64_t)P0 : 0;
@@ -566,6 +586,7 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                 if (a.host_status) *a.host_status = *a.status;
             }
             lds_barrier();
+            seg += nwg;
             continue;
         }
         uint32_t c = 0;
@@ -645,6 +666,15 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         }
         lds_barrier();
         JPG_STAMP(7);
+        if (ticketer) sSeg = ticket;
+        lds_barrier();
+        seg = sSeg;
+    }
+    // the last workgroup of the image to leave puts the counters back to 0 for the next launch (every
+    // workgroup has drawn its last ticket before it counts itself out)
+    if (STUFF && ticketer && atomicAdd(&a.ticket[1], 1u) == nwg - 1) {
+        __hip_atomic_store(&a.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -654,18 +684,18 @@ hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred
     const int nimg = b.nimg > 0 ? b.nimg : 1;
     if (nchunks != b.nchunks || b.cstride < nchunks || b.slot_words != CHUNK_STRIDE_WORDS || (nimg > 1 && g.nblocks >= (1LL << 31))) return hipErrorInvalidValue;
     // as many workgroups as fit on the device at once (each loops over its share of the chunks)
-    static long long resident_cache[64] = {};
+    static std::atomic<long long> resident_cache[64] = {};   // device properties, not state
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    long long resident = dev >= 0 && dev < 64 ? resident_cache[dev] : 0;
+    long long resident = dev >= 0 && dev < 64 ? resident_cache[dev].load(std::memory_order_relaxed) : 0;
     if (resident == 0) {
         int cus = 0, per_cu = 0;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_entropy<false>, ENT_THREADS, 0);
         if (e != hipSuccess) return e;
         resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
-        if (dev >= 0 && dev < 64) resident_cache[dev] = resident;
+        if (dev >= 0 && dev < 64) resident_cache[dev].store(resident, std::memory_order_relaxed);
     }
     const unsigned grid = (unsigned)min((nchunks * nimg + ENT_WAVES - 1) / ENT_WAVES, resident);
     EntArgs a{coef, g.nblocks, nchunks, nimg, b.cstride, g.nb, g.h * g.v, {pred[0], pred[1], pred[2]}, b.epoch, b.clen,
@@ -680,19 +710,20 @@ static hipError_t launch_stream(const EntropyBufs &b, uint64_t bit_offset, uint8
                                 size_t out_stride, hipStream_t s) {
     const int nimg = b.nimg > 0 ? b.nimg : 1;
     const int ngroups = (int)((b.nchunks + 63) / 64);
-    if (ngroups > MAX_GROUPS || !out || b.slot_words <= 0) return hipErrorInvalidValue;
+    if (ngroups > MAX_GROUPS || !out || b.slot_words <= 0 || (STUFF && !b.sticket)) return hipErrorInvalidValue;
     const size_t lds = (ngroups + 1) * sizeof(uint64_t);
-    // no more workgroups than fit on the device at once: a segment waits for the segments before it, which
-    // must therefore be running or finished whatever the dispatch order.  The figure depends on the dynamic
-    // LDS size; it is looked up once per size class (the size rounded up to 4 KiB).
+    // As many workgroups as fit on an idle device at once (more would only queue up; fewer being resident,
+    // because something else runs on the device, is harmless: segments are handed out in order by a ticket
+    // counter).  The figure depends on the dynamic LDS size; it is looked up once per size class (the size
+    // rounded up to 4 KiB).
     constexpr size_t LDS_CLASS = 4096;
     constexpr int NCLASS = (int)(((MAX_GROUPS + 1) * sizeof(uint64_t) + LDS_CLASS - 1) / LDS_CLASS) + 1;
-    static long long resident_cache[2][64][NCLASS] = {};
+    static std::atomic<long long> resident_cache[2][64][NCLASS] = {};   // device properties, not state
     const int cls = (int)((lds + LDS_CLASS - 1) / LDS_CLASS);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    long long resident = dev >= 0 && dev < 64 ? resident_cache[STUFF][dev][cls] : 0;
+    long long resident = dev >= 0 && dev < 64 ? resident_cache[STUFF][dev][cls].load(std::memory_order_relaxed) : 0;
     if (resident == 0) {
         int cus = 0, per_cu = 0;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -700,7 +731,7 @@ static hipError_t launch_stream(const EntropyBufs &b, uint64_t bit_offset, uint8
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<STUFF>, ST_THREADS, (size_t)cls * LDS_CLASS);
         if (e != hipSuccess) return e;
         resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
-        if (dev >= 0 && dev < 64) resident_cache[STUFF][dev][cls] = resident;
+        if (dev >= 0 && dev < 64) resident_cache[STUFF][dev][cls].store(resident, std::memory_order_relaxed);
     }
     size_t cap = (size_t)resident;
     if (b.stuff_grid && b.stuff_grid < cap) cap = b.stuff_grid;
@@ -709,7 +740,7 @@ static hipError_t launch_stream(const EntropyBufs &b, uint64_t bit_offset, uint8
     if (wpi > b.nseg_cap) wpi = b.nseg_cap ? b.nseg_cap : 1;
     StreamArgs a{b.sparse, b.clen, b.nchunks, ngroups, (int)wpi, b.cstride, (size_t)b.slot_words, out_stride, b.nseg_cap, b.nseg_cap / 64 + 1,
                  b.nseg_cap / 4096 + 1, b.status, (uint32_t)(bit_offset & 7), head_bits, is_last, b.sagg, b.sgrp, b.shyp,
-                 b.stuff_epoch, b.epoch, out, b.host_status, b.trace};
+                 b.sticket, b.stuff_epoch, b.epoch, out, b.host_status, b.trace};
     hipLaunchKernelGGL(k_stream<STUFF>, dim3((unsigned)(wpi * nimg)), dim3(ST_THREADS), lds, s, a);
     return hipGetLastError();
 }

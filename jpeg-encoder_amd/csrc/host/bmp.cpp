@@ -25,14 +25,19 @@ static int bmp_read(const char *path, jph_bmp *out, void *(*alloc)(size_t), void
     memset(out, 0, sizeof *out);
     FILE *f = fopen(path, "rb");
     if (!f) return JPH_ERR_OPEN;
-    uint8_t hdr[26];
+    uint8_t hdr[34];
     memset(hdr, 0, sizeof hdr);
     const size_t got = fread(hdr, 1, sizeof hdr, f);
     (void)got;  // short headers read as zeros, like the reference's ignored read results
     out->data_offset = rd_u32(hdr + 10);
     out->width = (int32_t)rd_u32(hdr + 18);
     out->height = (int32_t)rd_u32(hdr + 22);
-    if (out->width <= 0 || out->height <= 0) {
+    // The reference interprets nothing else and would read any other pixel format as 24-bit rows
+    // (the checks are TODOs at src/bmp/bmp_image.rs:22-24).  Refused here instead of encoding garbage:
+    // top-down files (negative height), empty images, anything but uncompressed 24 bits per pixel.
+    const unsigned bpp = (unsigned)hdr[28] | (unsigned)hdr[29] << 8;
+    const uint32_t compression = rd_u32(hdr + 30);
+    if (out->width <= 0 || out->height <= 0 || bpp != 24 || compression != 0) {
         fclose(f);
         return JPH_ERR_FORMAT;
     }

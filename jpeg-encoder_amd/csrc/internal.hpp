@@ -72,7 +72,8 @@ struct EntropyBufs {
     uint64_t *sgrp;        // [nimg][nseg_cap/64 + 1] ... of a group of 64 segments
     uint64_t *shyp;        // [nimg][nseg_cap/4096 + 1] ... of a hyper-group of 64 groups
     uint32_t stuff_epoch;  // their generation (1..16383)
-    size_t stuff_grid;     // workgroups of the stream kernels (all must be able to be resident)
+    uint32_t *sticket;     // [nimg][2] segment ticket counter and exit counter of the stuffing kernel; zero between launches
+    size_t stuff_grid;     // workgroups of the stream kernels (0 = as many as fit on the device)
     uint8_t *scan;         // [nimg][scan_stride] stuffed streams
     size_t scan_stride;    // bytes per image
     size_t nseg_cap;       // stuffing segments an image can have

@@ -58,28 +58,47 @@ def test_golden_fixtures_real_dct_strict(J, case):
     assert hashlib.sha256(data).hexdigest() == case["file_sha256"]
 
 
-def test_wikipedia_block_on_device(J):
+def _colour_with_luma(oracle, v):
+    """An (r, g, b) whose luma is exactly v in the reference's f32 formula (src/utils/colorspace.rs:5-15):
+    grey v gives v or v - 1 (13 of the 256 grey levels lose one to truncation), so look around it."""
+    for g in (v, v + 1, v - 1):
+        if 0 <= g <= 255 and oracle.rgb_to_ycbcr(g, g, g)[0] == v:
+            return (g, g, g)
+    for dg in (0, 1, -1, 2, -2):
+        for db in range(-8, 9):
+            r, g, b = v, min(255, max(0, v + dg)), min(255, max(0, v + db))
+            if oracle.rgb_to_ycbcr(r, g, b)[0] == v:
+                return (r, g, b)
+    raise AssertionError("no colour with luma %d" % v)
+
+
+def test_wikipedia_block_on_device(J, oracle):
+    """The reference's own DCT vector (src/jpeg/dct_quant.rs:242-322) through the device: pixels are chosen so
+    that the device's luma plane IS the block, then the reference's bound (mean |error| <= 1, :255,280) and the
+    oracle's exact coefficients are asserted for every transform, staged and fused."""
     ref = json.load(open(os.path.join(HERE, "golden", "reference_vectors.json")))["wikipedia_block"]
     blk = np.array(ref["input"], np.uint8).reshape(8, 8)
-    # a grey image whose luma plane is the block: R=G=B=v gives Y=v exactly for these values?  Not in
-    # general (f32 rounding), so feed the block through the staged planes instead: load, then compare
-    # the device's own Y plane with what the transform saw.
-    rows = np.zeros((8, 24), np.uint8)
-    rows[:, 0::3] = blk[::-1]
-    rows[:, 1::3] = blk[::-1]
-    rows[:, 2::3] = blk[::-1]
-    for algo, first in (("real-dct", None), ("bin-dct", None)):
+    rgb = np.array([_colour_with_luma(oracle, int(v)) for v in blk.reshape(-1)], np.uint8).reshape(8, 8, 3)
+    rows = np.ascontiguousarray(rgb[::-1, :, ::-1]).reshape(8, 24)           # bottom-up, B,G,R
+    first_rows = {"real-dct": [-25, -2, -6, 1, 2, 0, 0, 0, 0, -1, -4, 0, 0, 0, 0, 0],
+                  "real-dct-strict": [-25, -2, -6, 1, 2, 0, 0, 0, 0, -1, -4, 0, 0, 0, 0, 0],
+                  "bin-dct": [-51, -6, -8, 3, 2, -1, 0, 0, 0, -6, -7, 1, 0, 0, 0, 0]}
+    for algo in ("real-dct", "real-dct-strict", "bin-dct"):
         im = J.JpegImage.from_bgr_rows(rows, 8, 8, None, (4, 4, 4), algo)
-        y = im.y_channel
+        np.testing.assert_array_equal(im.y_channel, blk)                    # the transform sees the block itself
         im.chrominance_downsampling()
         im.dct_and_quantization()
-        got = im.y_dct_coeffs.reshape(-1)
-        if np.array_equal(y, blk):                                # the colour conversion kept the block intact
-            assert np.abs(got - np.array(ref["expected"])).mean() <= ref["mean_abs_error_threshold"]
-            if algo == "bin-dct":
-                assert got[:8].tolist() == [-51, -6, -8, 3, 2, -1, 0, 0]
-            else:
-                assert got[:8].tolist() == [-25, -2, -6, 1, 2, 0, 0, 0]
+        got = im.y_dct_coeffs.reshape(-1).astype(np.int32)
+        assert np.abs(got - np.array(ref["expected"])).mean() <= ref["mean_abs_error_threshold"]
+        want = oracle.bin_dct_block(blk) if algo == "bin-dct" else oracle.real_dct_block(blk, cos_mode=oracle.COS_CALL)
+        if algo == "real-dct":                                              # separable: +-1 at truncation boundaries
+            assert np.abs(got - want).max() <= 1
+        else:
+            assert got[:16].tolist() == first_rows[algo]
+            np.testing.assert_array_equal(got, want.astype(np.int32))
+        enc = J.Encoder((4, 4, 4), algo)                                    # the fused kernel
+        enc.encode_scan(rows, 8, 8)
+        np.testing.assert_array_equal(enc.coeffs(0).reshape(-1), got)
 
 
 # ---- extreme content: long blocks (more than 128 bits, several LDS passes), ZRL runs, 0xFF bytes

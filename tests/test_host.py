@@ -46,7 +46,7 @@ def test_error_strings_are_the_reference_panics(J):
     assert L.jpg_strerror(-3) == b"AC coefficient bit length greater than 10!"     # src/jpeg/entropy_coding.rs:190
     assert L.jpg_strerror(-4) == b"DC Huffman Code Not Found!"
     assert L.jpg_strerror(-5) == b"AC Huffman Code Not Found!"
-    for code in range(-11, 1):
+    for code in range(-12, 1):
         assert L.jpg_strerror(code) != b"unknown status"
 
 
@@ -100,7 +100,8 @@ def test_bmp_roundtrip_and_oracle_agreement(J, oracle, tmp_path, w, h):
 
 
 def test_bmp_reader_uses_only_three_header_fields(J, oracle, tmp_path):
-    """data offset @10, width @18, height @22; everything else is ignored, as in the reference."""
+    """data offset @10, width @18, height @22 locate the pixels, as in the reference; of the rest only the
+    pixel format (24 bits, uncompressed) is looked at, to refuse what the reference would misread."""
     w, h = 7, 5
     rows = J.host.synth_bgr(w, h, seed=3)
     stride = J.host.bmp_stride(w)
@@ -109,6 +110,7 @@ def test_bmp_reader_uses_only_three_header_fields(J, oracle, tmp_path):
     struct.pack_into("<I", hdr, 10, off)
     struct.pack_into("<i", hdr, 18, w)
     struct.pack_into("<i", hdr, 22, h)
+    struct.pack_into("<HI", hdr, 28, 24, 0)
     p = str(tmp_path / "v5.bmp")
     open(p, "wb").write(bytes(hdr) + rows.tobytes())
     got, gw, gh, gs = J.host.read_bmp(p)
@@ -127,6 +129,33 @@ def test_bmp_errors(J, tmp_path):
     open(p, "wb").write(bytes(hdr))
     with pytest.raises(J.host.BmpError):
         J.host.read_bmp(p)
+
+
+@pytest.mark.parametrize("field,value", [("bpp", 32), ("bpp", 8), ("bpp", 0), ("compression", 1), ("compression", 3),
+                                         ("height", -5), ("width", -7)])
+def test_bmp_rejects_other_pixel_formats(J, tmp_path, field, value):
+    """What the reference leaves as TODOs (src/bmp/bmp_image.rs:22-24) and would read as 24-bit rows:
+    other depths, compressed data, top-down (negative height) files -> JPH_ERR_FORMAT, nothing encoded."""
+    import ctypes as C
+    w, h = 6, 5
+    rows = J.host.synth_bgr(w, h, seed=2)
+    p = str(tmp_path / "x.bmp")
+    J.host.write_bmp(p, rows, w, h)
+    J.host.read_bmp(p)                                           # fine as written
+    raw = bytearray(open(p, "rb").read())
+    if field == "bpp":
+        struct.pack_into("<H", raw, 28, value)
+    elif field == "compression":
+        struct.pack_into("<I", raw, 30, value)
+    elif field == "height":
+        struct.pack_into("<i", raw, 22, value)
+    else:
+        struct.pack_into("<i", raw, 18, value)
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(J.host.BmpError, match="status -2"):
+        J.host.read_bmp(p)
+    b = J.host._Bmp()
+    assert J.host.lib().jph_bmp_read(p.encode(), C.byref(b)) == -2 and not b.pixels
 
 
 def test_synth_is_deterministic_and_seeded(J):
