@@ -6,9 +6,11 @@
  * 61,66).  Each entry point below replaces one of them (cited per function)
  * with plain pointers and sizes, so a Rust/C/C++/Python host can bind it.
  *
- * Threading: a context owns its device buffers and one HIP stream.  A context
+ * Threading: a context owns its device buffers and its HIP streams.  A context
  * is thread-compatible (one thread at a time), not thread-safe.  The library
- * keeps no global mutable state.
+ * keeps no global mutable state apart from per-device caches of device
+ * properties (atomics).  Every entry point makes the context's device current
+ * for its own duration and restores the caller's current device on return.
  *
  * Errors: every function returns 0 (JPG_OK) or a negative jpg_status.  The
  * library never aborts; jpg_strerror() gives the reference's panic text where
@@ -140,6 +142,9 @@ int jpg_get_batch_scan(jpg_ctx *ctx, int32_t i, uint8_t *out, size_t cap);
  * the reference. */
 int jpg_set_timing(jpg_ctx *ctx, int every);
 int jpg_front_time(jpg_ctx *ctx, double *total_ms, uint64_t *launches, uint64_t *images);
+/* the individual durations (milliseconds) of the first up to 4096 of those launches, in launch order: *n of
+ * them are written to ms[0..cap) */
+int jpg_front_samples(jpg_ctx *ctx, float *ms, int32_t cap, int32_t *n);
 /* Page-locked host memory (release with jpg_free).  Rows handed to jpg_load_bgr,
  * jpg_front_host or jpg_encode_scan from such memory are copied by DMA at full
  * link speed; ordinary (pageable) memory is staged through the library's own
@@ -186,13 +191,54 @@ int jpg_last_dc(jpg_ctx *ctx, int16_t dc[3]);
 int jpg_stitch(jpg_ctx *ctx, uint64_t bit_offset, uint8_t head_bits, int is_last, size_t *len,
                uint8_t *tail);
 
+/* A stripe from device-resident rows the caller keeps valid until the stripe has been coded (jpg_entropy_stripe
+ * or jpg_entropy_stripe_finish has returned).  Where the single coding kernel applies (see
+ * jpg_encode_device_async) nothing is computed by this call: jpg_last_dc transforms the stripe's last MCU only
+ * and the coding call goes from the rows to the coded bits in one kernel; jpg_get_coeffs still works. */
+int jpg_stripe_device(jpg_ctx *ctx, const uint8_t *dev_pixels, int32_t width, int32_t height, uint32_t row_stride,
+                      int bottom_up);
+/* jpg_front_host without the wait for the copy: `pixels` (host memory) must stay valid and unchanged until a
+ * later call on the context has waited (jpg_last_dc, jpg_entropy_stripe*, jpg_sync).  Lets the host-to-device
+ * copies of the stripes of several contexts run at the same time. */
+int jpg_stripe_host_async(jpg_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t height, uint32_t row_stride,
+                          int bottom_up);
+/* The three steps of a stripe without waiting in between, so that one host thread can keep the stripes of
+ * several contexts (one per GPU) running at the same time: *_async queues on the context's stream, the
+ * matching call waits for it and reports.
+ *   jpg_last_dc_async           -> jpg_last_dc
+ *   jpg_entropy_stripe_async    -> jpg_entropy_stripe_finish (also the stripe's last bits: jpg_stream_tail)
+ *   jpg_stitch_async            -> jpg_stitch_finish */
+int jpg_last_dc_async(jpg_ctx *ctx);
+int jpg_entropy_stripe_async(jpg_ctx *ctx, const int16_t pred[3]);
+int jpg_entropy_stripe_finish(jpg_ctx *ctx, uint64_t *nbits, uint32_t *last32);
+int jpg_stitch_async(jpg_ctx *ctx, uint64_t bit_offset, uint8_t head_bits, int is_last);
+int jpg_stitch_finish(jpg_ctx *ctx, size_t *len, uint8_t *tail);
+/* Gathering the pieces: copies the context's stuffed piece (after jpg_stitch) to `dst` in device memory,
+ * queued on the context's stream (jpg_sync waits).  dst_device >= 0 and different from the context's device:
+ * a peer copy between the two GPUs (hipMemcpyPeerAsync, over xGMI where the GPUs are linked); dst_device < 0 or
+ * the same device: `dst` is any address this process can write by unified addressing, e.g. a buffer of
+ * another process opened with jpg_ipc_open.  cap = bytes available at dst. */
+int jpg_scan_copy_to_device(jpg_ctx *ctx, void *dst, int dst_device, size_t cap);
+/* Plain device memory for the gathered scan, for hosts that do not link the HIP runtime themselves, a blocking
+ * copy of it to the host (waits for everything queued on the device first), and its hand-over between
+ * processes (one process per GPU): the owner exports a handle, the others open it on their own device and
+ * copy their pieces in.  No counterpart in the reference. */
+void *jpg_device_alloc(int device, size_t bytes);
+void jpg_device_free(int device, void *p);
+int jpg_device_to_host(int device, void *dst, const void *src_dev, size_t bytes);
+#define JPG_IPC_HANDLE_BYTES 64
+int jpg_ipc_export(const void *dev_ptr, uint8_t handle[JPG_IPC_HANDLE_BYTES]);
+int jpg_ipc_open(int device, const uint8_t handle[JPG_IPC_HANDLE_BYTES], void **dev_ptr);
+int jpg_ipc_close(void *dev_ptr);
+
 /* ---- results ------------------------------------------------------------ */
 
 /* device pointers of the current results (valid until the next call that
  * re-encodes or destroys the context) */
 const uint8_t *jpg_bits_device(jpg_ctx *ctx);
 const uint8_t *jpg_scan_device(jpg_ctx *ctx);
-/* copies to host memory; cap = capacity of `out` in bytes */
+/* copies to host memory; cap = capacity of `out` in bytes.  The bit string is assembled on the first request
+ * (jpg_bits_device / jpg_get_bits); JPG_ERR_STATE while queued encodes have not been taken with jpg_finish*. */
 int jpg_get_bits(jpg_ctx *ctx, uint8_t *out, size_t cap);
 int jpg_get_scan(jpg_ctx *ctx, uint8_t *out, size_t cap);
 /* public fields y_channel..cr_dct_coeffs of JpegImage (src/jpeg/jpeg_image.rs:

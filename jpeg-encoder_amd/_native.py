@@ -22,7 +22,11 @@ SYMBOLS = [
     "jpg_entropy_stripe", "jpg_stream_tail", "jpg_last_dc", "jpg_stitch", "jpg_bits_device", "jpg_scan_device",
     "jpg_get_bits", "jpg_get_scan", "jpg_plane_dims", "jpg_coeff_dims", "jpg_get_plane", "jpg_get_coeffs",
     "jpg_front_bytes", "jpg_num_blocks", "jpg_fused_coding",
+    "jpg_front_samples", "jpg_stripe_device", "jpg_stripe_host_async", "jpg_last_dc_async", "jpg_entropy_stripe_async", "jpg_entropy_stripe_finish",
+    "jpg_stitch_async", "jpg_stitch_finish", "jpg_scan_copy_to_device", "jpg_device_alloc", "jpg_device_free",
+    "jpg_device_to_host", "jpg_ipc_export", "jpg_ipc_open", "jpg_ipc_close",
 ]
+IPC_HANDLE_BYTES = 64
 
 
 class JpgError(RuntimeError):
@@ -74,7 +78,7 @@ def lib():
     L.jpg_stream.restype = vp
     L.jpg_sync.argtypes = [vp]
     for name in ("jpg_load_bgr", "jpg_load_bgr_device", "jpg_front_device", "jpg_front_host",
-                 "jpg_encode_device_async"):
+                 "jpg_encode_device_async", "jpg_stripe_device", "jpg_stripe_host_async"):
         getattr(L, name).argtypes = [vp, vp, i32, i32, u32, C.c_int]
     L.jpg_downsample.argtypes = [vp]
     L.jpg_dct_quant.argtypes = [vp]
@@ -113,6 +117,21 @@ def lib():
     L.jpg_num_blocks.restype = C.c_uint64
     L.jpg_fused_coding.argtypes = [vp]
     L.jpg_fused_coding.restype = C.c_int
+    L.jpg_front_samples.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(i32)]
+    L.jpg_last_dc_async.argtypes = [vp]
+    L.jpg_entropy_stripe_async.argtypes = [vp, C.POINTER(C.c_int16)]
+    L.jpg_entropy_stripe_finish.argtypes = [vp, u64p, C.POINTER(C.c_uint32)]
+    L.jpg_stitch_async.argtypes = [vp, C.c_uint64, C.c_uint8, C.c_int]
+    L.jpg_stitch_finish.argtypes = [vp, szp, C.POINTER(C.c_uint8)]
+    L.jpg_scan_copy_to_device.argtypes = [vp, vp, C.c_int, C.c_size_t]
+    L.jpg_device_alloc.argtypes = [C.c_int, C.c_size_t]
+    L.jpg_device_alloc.restype = vp
+    L.jpg_device_free.argtypes = [C.c_int, vp]
+    L.jpg_device_free.restype = None
+    L.jpg_device_to_host.argtypes = [C.c_int, vp, vp, C.c_size_t]
+    L.jpg_ipc_export.argtypes = [vp, C.POINTER(C.c_uint8)]
+    L.jpg_ipc_open.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.POINTER(vp)]
+    L.jpg_ipc_close.argtypes = [vp]
     _lib = L
     return L
 

@@ -68,7 +68,13 @@ struct jpg_ctx {
     double t_total_ms = 0.0;
     uint64_t t_count = 0, t_images = 0;
     int t_imgs[TIMING_RING] = {};   // images of each pending launch
+    static constexpr int TIMING_KEEP = 4096;
+    float t_sample[TIMING_KEEP] = {};   // duration of each harvested launch, in milliseconds (the first TIMING_KEEP)
     int16_t *h_dc = nullptr;        // pinned
+    bool rows_lent = false;         // d_src points at rows the caller keeps alive until the stripe is coded (jpg_stripe_device)
+    bool dc_pending = false;        // jpg_last_dc_async has queued the copy into h_dc
+    bool code_pending = false;      // jpg_entropy_stripe_async has queued the coding of the stripe
+    bool stitch_pending = false;    // jpg_stitch_async has queued the stuffing of the stripe
 };
 
 static inline jpg_ctx::Slot &S(jpg_ctx *c) { return c->slot[c->cur]; }          // being written
@@ -259,6 +265,7 @@ static int set_geometry(jpg_ctx *c, int32_t W, int32_t H, uint32_t stride, int b
     c->g = g;
     c->nimg = 1;
     c->stage = ST_NONE; c->have_planes = false; c->down_done = false; c->coef_valid = false;
+    c->rows_lent = false; c->dc_pending = false; c->code_pending = false; c->stitch_pending = false;
     return JPG_OK;
 }
 
@@ -481,6 +488,7 @@ static int harvest_timing(jpg_ctx *c) {
         float ms = 0.0f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->t_ev[2 * k], c->t_ev[2 * k + 1]));
         c->t_total_ms += ms;
+        if (c->t_count < (uint64_t)jpg_ctx::TIMING_KEEP) c->t_sample[c->t_count] = ms;
         c->t_count++;
         c->t_images += (uint64_t)c->t_imgs[k];
     }
@@ -532,6 +540,18 @@ extern "C" int jpg_set_timing(jpg_ctx *c, int every) {
     c->t_images = 0;
     c->t_seen = 0;
     c->timing = every > 0 ? every : 0;
+    return JPG_OK;
+}
+
+extern "C" int jpg_front_samples(jpg_ctx *c, float *ms, int32_t cap, int32_t *n) {
+    if (!c || !n || (cap > 0 && !ms)) return JPG_ERR_BAD_ARG;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int e = harvest_timing(c)) return e;
+    const uint64_t have = c->t_count < (uint64_t)jpg_ctx::TIMING_KEEP ? c->t_count : (uint64_t)jpg_ctx::TIMING_KEEP;
+    *n = (int32_t)(have < (uint64_t)(cap > 0 ? cap : 0) ? have : (uint64_t)(cap > 0 ? cap : 0));
+    for (int32_t k = 0; k < *n; k++) ms[k] = c->t_sample[k];
     return JPG_OK;
 }
 
@@ -619,7 +639,9 @@ static int make_dense(jpg_ctx *c) {
 
 // The fused coding kernel leaves no coefficients behind.  When they are asked for afterwards they are
 // computed from the context's own copy of the rows; rows the caller owns may be gone by then.
-static bool own_rows(const jpg_ctx *c) { return c->nimg == 1 && c->d_src && c->d_src == c->d_src_own; }
+static bool own_rows(const jpg_ctx *c) {
+    return c->nimg == 1 && c->d_src && (c->d_src == c->d_src_own || c->rows_lent);
+}
 
 static int need_coef(jpg_ctx *c) {
     if (c->coef_valid) return JPG_OK;
@@ -632,11 +654,9 @@ static bool code_from_rows(const jpg_ctx *c) {
     return !c->coef_valid && own_rows(c) && !c->two_kernels && coded_supported(c->g);
 }
 
-static int entropy_common(jpg_ctx *c, const int16_t *pred, uint64_t *nbits) {
-    if (!c) return JPG_ERR_BAD_ARG;
-    if (c->stage < ST_COEF) return JPG_ERR_STATE;
-    DeviceGuard dg;
-    if (int e = use_device(c, dg)) return e;
+// Queue the coding of the current image (or stripe, from the predictors `pred`) and the kernel that sums up
+// its length and picks out its last bits; nothing is waited for.
+static int queue_coding(jpg_ctx *c, const int16_t *pred) {
     c->npend = 0;
     if (code_from_rows(c)) {
         // no coefficients were asked for so far: one kernel from the rows to the coded tiles
@@ -646,13 +666,29 @@ static int entropy_common(jpg_ctx *c, const int16_t *pred, uint64_t *nbits) {
         if (int e = need_coef(c)) return e;
         if (int e = queue_entropy(c, pred)) return e;
     }
-    if (int e = make_dense(c)) return e;
+    HIP_TRY(c, launch_tail(S(c).eb, c->stream));
+    return JPG_OK;
+}
+
+static int finish_coding(jpg_ctx *c, uint64_t *nbits, uint32_t *last32) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->code_pending = false;
     jpg_ctx::Slot &sl = S(c);
     if (int ke = kernel_error(sl)) return ke;
     sl.nbits = sl.h_status->nbits;
     if (nbits) *nbits = sl.nbits;
+    if (last32) *last32 = sl.h_status->last32;
     c->stage = ST_BITS;
     return JPG_OK;
+}
+
+static int entropy_common(jpg_ctx *c, const int16_t *pred, uint64_t *nbits) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_COEF) return JPG_ERR_STATE;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    if (int e = queue_coding(c, pred)) return e;
+    return finish_coding(c, nbits, nullptr);
 }
 
 extern "C" int jpg_entropy(jpg_ctx *c, uint64_t *nbits) { return entropy_common(c, nullptr, nbits); }
@@ -661,34 +697,32 @@ extern "C" int jpg_entropy_stripe(jpg_ctx *c, const int16_t pred[3], uint64_t *n
     return entropy_common(c, pred, nbits);
 }
 
-extern "C" int jpg_stream_tail(jpg_ctx *c, uint32_t *last32) {
-    if (!c || !last32) return JPG_ERR_BAD_ARG;
-    if (c->stage < ST_BITS || c->npend) return JPG_ERR_STATE;
-    DeviceGuard dg;
-    if (int e = use_device(c, dg)) return e;
-    if (int e = make_dense(c)) return e;
-    const jpg_ctx::Slot &sl = V(c);
-    const uint64_t nbytes = (sl.nbits + 7) >> 3;
-    const uint64_t take = nbytes < 5 ? nbytes : 5;   // 32 bits may straddle 5 bytes
-    uint8_t b[8] = {0};
-    if (take) {
-        HIP_TRY(c, hipMemcpyAsync(b, reinterpret_cast<const uint8_t *>(sl.eb.bits) + (nbytes - take), take,
-                                  hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    uint64_t v = 0;
-    for (uint64_t i = 0; i < take; i++) v = (v << 8) | b[i];
-    const unsigned pad = (unsigned)(nbytes * 8 - sl.nbits);   // zero bits after the stream in its last byte
-    v >>= pad;
-    *last32 = (uint32_t)(sl.nbits >= 32 ? v : v & ((1ull << sl.nbits) - 1));
-    return JPG_OK;
-}
-
-extern "C" int jpg_last_dc(jpg_ctx *c, int16_t dc[3]) {
-    if (!c || !dc) return JPG_ERR_BAD_ARG;
+extern "C" int jpg_entropy_stripe_async(jpg_ctx *c, const int16_t pred[3]) {
+    if (!c || !pred) return JPG_ERR_BAD_ARG;
     if (c->stage < ST_COEF) return JPG_ERR_STATE;
     DeviceGuard dg;
     if (int e = use_device(c, dg)) return e;
+    if (int e = queue_coding(c, pred)) return e;
+    c->code_pending = true;
+    return JPG_OK;
+}
+
+extern "C" int jpg_entropy_stripe_finish(jpg_ctx *c, uint64_t *nbits, uint32_t *last32) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (!c->code_pending) return JPG_ERR_STATE;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    return finish_coding(c, nbits, last32);
+}
+
+extern "C" int jpg_stream_tail(jpg_ctx *c, uint32_t *last32) {
+    if (!c || !last32) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_BITS || c->npend || c->code_pending) return JPG_ERR_STATE;
+    *last32 = V(c).h_status->last32;   // left there by the kernel that measured the stream
+    return JPG_OK;
+}
+
+static int queue_last_dc(jpg_ctx *c) {
     if (code_from_rows(c)) {
         HIP_TRY(c, launch_last_dc_pixels(c->g, c->algo, c->d_src, c->d_dc, c->stream));
     } else {
@@ -696,24 +730,150 @@ extern "C" int jpg_last_dc(jpg_ctx *c, int16_t dc[3]) {
         HIP_TRY(c, launch_last_dc(c->g, c->d_coef, c->d_dc, c->stream));
     }
     HIP_TRY(c, hipMemcpyAsync(c->h_dc, c->d_dc, 3 * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+    c->dc_pending = true;
+    return JPG_OK;
+}
+
+extern "C" int jpg_last_dc_async(jpg_ctx *c) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_COEF) return JPG_ERR_STATE;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    return queue_last_dc(c);
+}
+
+extern "C" int jpg_last_dc(jpg_ctx *c, int16_t dc[3]) {
+    if (!c || !dc) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_COEF) return JPG_ERR_STATE;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    if (!c->dc_pending)
+        if (int e = queue_last_dc(c)) return e;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->dc_pending = false;
     dc[0] = c->h_dc[0]; dc[1] = c->h_dc[1]; dc[2] = c->h_dc[2];
     return JPG_OK;
 }
 
-extern "C" int jpg_stitch(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, int is_last, size_t *len, uint8_t *tail) {
-    if (!c) return JPG_ERR_BAD_ARG;
-    if (c->stage < ST_BITS || c->npend) return JPG_ERR_STATE;
-    DeviceGuard dg;
-    if (int e = use_device(c, dg)) return e;
-    if (int e = queue_stuff(c, bit_offset, head_bits, is_last, c->stream)) return e;
+static int finish_stitch(jpg_ctx *c, size_t *len, uint8_t *tail) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stitch_pending = false;
     jpg_ctx::Slot &sl = S(c);
     if (int ke = kernel_error(sl)) return ke;
     sl.scan_len = (size_t)sl.h_status->scan_bytes;
     if (len) *len = sl.scan_len;
     if (tail) *tail = (uint8_t)sl.h_status->tail;
     c->stage = ST_SCAN;
+    return JPG_OK;
+}
+
+extern "C" int jpg_stitch_async(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, int is_last) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_BITS || c->npend || c->code_pending) return JPG_ERR_STATE;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    if (int e = queue_stuff(c, bit_offset, head_bits, is_last, c->stream)) return e;
+    c->stitch_pending = true;
+    return JPG_OK;
+}
+
+extern "C" int jpg_stitch_finish(jpg_ctx *c, size_t *len, uint8_t *tail) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    if (!c->stitch_pending) return JPG_ERR_STATE;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    return finish_stitch(c, len, tail);
+}
+
+extern "C" int jpg_stitch(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, int is_last, size_t *len, uint8_t *tail) {
+    if (int e = jpg_stitch_async(c, bit_offset, head_bits, is_last)) return e;
+    return jpg_stitch_finish(c, len, tail);
+}
+
+// ---- gathering the pieces of a striped scan in one device buffer
+
+extern "C" int jpg_scan_copy_to_device(jpg_ctx *c, void *dst, int dst_device, size_t cap) {
+    if (!c || !dst) return JPG_ERR_BAD_ARG;
+    if (c->stage < ST_SCAN || c->stitch_pending) return JPG_ERR_STATE;
+    const jpg_ctx::Slot &sl = V(c);
+    if (cap < sl.scan_len) return JPG_ERR_CAPACITY;
+    if (!sl.scan_len) return JPG_OK;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    if (dst_device < 0 || dst_device == c->device) {
+        // the same device, or memory of another process opened with jpg_ipc_open (unified addressing finds it)
+        HIP_TRY(c, hipMemcpyAsync(dst, sl.eb.scan, sl.scan_len, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        HIP_TRY(c, hipMemcpyPeerAsync(dst, dst_device, sl.eb.scan, c->device, sl.scan_len, c->stream));
+    }
+    return JPG_OK;
+}
+
+extern "C" void *jpg_device_alloc(int device, size_t bytes) {
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+    void *p = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
+        p = nullptr;
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return p;
+}
+
+extern "C" void jpg_device_free(int device, void *p) {
+    if (!p) return;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+    if (hipSetDevice(device) == hipSuccess) (void)hipFree(p);
+    (void)hipGetLastError();
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+extern "C" int jpg_device_to_host(int device, void *dst, const void *src_dev, size_t bytes) {
+    if (!dst || !src_dev) return JPG_ERR_BAD_ARG;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+    bool ok = hipSetDevice(device) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+              hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return ok ? JPG_OK : JPG_ERR_HIP;
+}
+
+static_assert(sizeof(hipIpcMemHandle_t) == JPG_IPC_HANDLE_BYTES, "handle size of the C ABI");
+
+extern "C" int jpg_ipc_export(const void *dev_ptr, uint8_t handle[JPG_IPC_HANDLE_BYTES]) {
+    if (!dev_ptr || !handle) return JPG_ERR_BAD_ARG;
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, const_cast<void *>(dev_ptr)) != hipSuccess) {
+        (void)hipGetLastError();
+        return JPG_ERR_HIP;
+    }
+    memcpy(handle, &h, sizeof h);
+    return JPG_OK;
+}
+
+extern "C" int jpg_ipc_open(int device, const uint8_t handle[JPG_IPC_HANDLE_BYTES], void **dev_ptr) {
+    if (!handle || !dev_ptr) return JPG_ERR_BAD_ARG;
+    *dev_ptr = nullptr;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof h);
+    const bool ok = hipSetDevice(device) == hipSuccess &&
+                    hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return ok ? JPG_OK : JPG_ERR_HIP;
+}
+
+extern "C" int jpg_ipc_close(void *dev_ptr) {
+    if (!dev_ptr) return JPG_ERR_BAD_ARG;
+    if (hipIpcCloseMemHandle(dev_ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return JPG_ERR_HIP;
+    }
     return JPG_OK;
 }
 
@@ -731,13 +891,31 @@ extern "C" int jpg_front_device(jpg_ctx *c, const uint8_t *dev_pixels, int32_t W
     return JPG_OK;
 }
 
-extern "C" int jpg_front_host(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride, int bottom_up) {
+extern "C" int jpg_stripe_device(jpg_ctx *c, const uint8_t *dev_pixels, int32_t W, int32_t H, uint32_t stride,
+                                 int bottom_up) {
+    if (!c || !dev_pixels) return JPG_ERR_BAD_ARG;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
+    if (int e = stage_input(c, dev_pixels, false)) return e;
+    // Rows the caller keeps alive until the stripe is coded: where the single coding kernel applies nothing is
+    // computed yet (jpg_last_dc transforms the last MCU, jpg_entropy_stripe codes straight from the rows)
+    c->rows_lent = true;
+    if (!c->two_kernels && coded_supported(c->g)) c->coef_valid = false;
+    else if (int e = queue_front(c)) return e;
+    c->stage = ST_COEF;
+    return JPG_OK;
+}
+
+// rows from host memory into the context's own device copy; wait: until the caller may reuse `pixels`
+static int front_host_common(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride, int bottom_up,
+                             bool wait) {
     if (!c || !pixels) return JPG_ERR_BAD_ARG;
     DeviceGuard dg;
     if (int e = use_device(c, dg)) return e;
     if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
     if (int e = stage_input(c, pixels, true)) return e;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));   // caller may reuse `pixels`
+    if (wait) HIP_TRY(c, hipStreamSynchronize(c->stream));
     // The context now holds its own copy of the rows.  Where the single coding kernel applies, the
     // transform waits for the call that tells what is wanted: coefficients (jpg_get_coeffs: front kernel)
     // or bits (jpg_entropy, jpg_entropy_stripe: coding kernel, no coefficients in memory).
@@ -745,6 +923,15 @@ extern "C" int jpg_front_host(jpg_ctx *c, const uint8_t *pixels, int32_t W, int3
     else if (int e = queue_front(c)) return e;
     c->stage = ST_COEF;
     return JPG_OK;
+}
+
+extern "C" int jpg_front_host(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride, int bottom_up) {
+    return front_host_common(c, pixels, W, H, stride, bottom_up, true);
+}
+
+extern "C" int jpg_stripe_host_async(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride,
+                                     int bottom_up) {
+    return front_host_common(c, pixels, W, H, stride, bottom_up, false);
 }
 
 // A whole encode of the staged rows (or of the batch srcs[0..n-1]): coding on `stream`, stuffing on

@@ -678,6 +678,44 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     }
 }
 
+// Length and last bits of the stream the chunks add up to, for a stripe: what the stripes after it need
+// (where their bits start, and the bits that share a byte with their first ones) before anything is
+// assembled.  One workgroup: a 64-bit sum of the chunk lengths, then one thread walks back from the last
+// chunk until it has 32 bits.
+__global__ __launch_bounds__(256) void k_tail(const uint32_t *__restrict__ sparse, const uint32_t *__restrict__ clen,
+                                              long long nchunks, size_t slot_words, DevStatus *status, DevStatus *host_status) {
+    __shared__ uint64_t sSum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t sum = 0;
+    for (long long c = tid; c < nchunks; c += 256) sum += clen[c];
+    sum = wave_sum64(sum);
+    if (lane == 0) sSum[wave] = sum;
+    __syncthreads();
+    if (tid != 0) return;
+    const uint64_t nbits = sSum[0] + sSum[1] + sSum[2] + sSum[3];
+    uint32_t acc = 0, got = 0;
+    for (long long c = nchunks - 1; c >= 0 && got < 32; c--) {
+        const uint32_t L = clen[c];
+        if (L == 0) continue;
+        const uint32_t take = min(32u - got, L), first = L - take;      // bits [first, L) of the chunk, MSB first
+        const uint32_t *w = sparse + (size_t)c * slot_words + (first >> 5);
+        const uint64_t two = ((uint64_t)w[0] << 32) | (((first & 31) + take > 32) ? w[1] : 0u);
+        const uint32_t v = (uint32_t)((two << (first & 31)) >> (64 - take));
+        acc |= got < 32 ? v << got : 0u;
+        got += take;
+    }
+    status->nbits = nbits;
+    status->last32 = acc;
+    if (host_status) *host_status = *status;
+}
+
+hipError_t launch_tail(const EntropyBufs &b, hipStream_t s) {
+    if ((b.nimg > 0 ? b.nimg : 1) != 1 || b.slot_words <= 0) return hipErrorInvalidValue;   // single images only
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3(256), 0, s, b.sparse, b.clen, b.nchunks, (size_t)b.slot_words, b.status,
+                       b.host_status);
+    return hipGetLastError();
+}
+
 hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred[3], const EntropyBufs &b,
                           hipStream_t s) {
     const long long nchunks = (g.nblocks + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;

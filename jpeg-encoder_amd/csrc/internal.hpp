@@ -50,6 +50,8 @@ struct DevStatus {
     uint64_t scan_bytes;  // bytes of the stuffed stream
     int32_t error;        // sticky jpg_status raised by a kernel (0 = none)
     uint32_t tail;        // bits of the dropped partial byte (stripes)
+    uint32_t last32;      // the last min(32, nbits) bits of the unstuffed stream, right-aligned (stripes)
+    uint32_t reserved;
 };
 
 // A "chunk" is the unit whose bits one kernel assembles on its own: 64 consecutive blocks
@@ -110,6 +112,9 @@ hipError_t launch_last_dc_pixels(const Geom &g, int algo, const uint8_t *src, in
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s);
 // writes the dense stream to b.bits
 hipError_t launch_dense(const EntropyBufs &b, hipStream_t s);
+// sums the chunk lengths and picks the last 32 bits of the stream out of the last chunks: status->nbits,
+// status->last32 (and the host copy), without assembling the stream (single images)
+hipError_t launch_tail(const EntropyBufs &b, hipStream_t s);
 // most images one launch of the stream kernels can take
 int max_batch_images();
 

@@ -110,6 +110,37 @@ class Encoder:
         self._ck(self._L.jpg_last_dc(self._ctx, dc))
         return tuple(dc)
 
+    # the same steps queued without waiting (one host thread driving several contexts)
+    def last_dc_async(self):
+        self._ck(self._L.jpg_last_dc_async(self._ctx))
+
+    def entropy_stripe_async(self, pred):
+        p = (C.c_int16 * 3)(*[int(x) for x in pred])
+        self._ck(self._L.jpg_entropy_stripe_async(self._ctx, p))
+
+    def entropy_stripe_finish(self):
+        """(nbits, last min(32, nbits) bits right-aligned) of the stripe queued with entropy_stripe_async."""
+        n, t = C.c_uint64(), C.c_uint32()
+        self._ck(self._L.jpg_entropy_stripe_finish(self._ctx, C.byref(n), C.byref(t)))
+        return n.value, t.value
+
+    def stitch_async(self, bit_offset, head_bits, is_last):
+        self._ck(self._L.jpg_stitch_async(self._ctx, bit_offset, head_bits, int(is_last)))
+
+    def stitch_finish(self):
+        n, tail = C.c_size_t(), C.c_uint8()
+        self._ck(self._L.jpg_stitch_finish(self._ctx, C.byref(n), C.byref(tail)))
+        return n.value, tail.value
+
+    def stripe_device(self, dev_ptr, width, height, stride, bottom_up=True):
+        """A stripe from device-resident rows that stay valid until the stripe is coded."""
+        self.width, self.height = width, height
+        self._ck(self._L.jpg_stripe_device(self._ctx, dev_ptr, width, height, stride, int(bottom_up)))
+
+    def scan_copy_to_device(self, dst_ptr, dst_device, cap):
+        """Queue the copy of the stuffed piece to device memory (a peer copy when dst_device is another GPU)."""
+        self._ck(self._L.jpg_scan_copy_to_device(self._ctx, dst_ptr, dst_device, cap))
+
     # ---- fused path ------------------------------------------------------
     def front_device(self, dev_ptr, width, height, stride, bottom_up=True):
         self.width, self.height = width, height
@@ -219,6 +250,13 @@ class Encoder:
         ms, n, im = C.c_double(), C.c_uint64(), C.c_uint64()
         self._ck(self._L.jpg_front_time(self._ctx, C.byref(ms), C.byref(n), C.byref(im)))
         return ms.value, n.value, im.value
+
+    def front_samples(self):
+        """Durations (ms) of the individual time-stamped launches since set_timing, in launch order."""
+        buf = (C.c_float * 4096)()
+        n = C.c_int32()
+        self._ck(self._L.jpg_front_samples(self._ctx, buf, 4096, C.byref(n)))
+        return [float(buf[k]) for k in range(n.value)]
 
     def front_bytes(self):
         return self._L.jpg_front_bytes(self._ctx)

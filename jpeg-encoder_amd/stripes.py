@@ -7,7 +7,8 @@ src/jpeg/entropy_coding.rs:38-40,149-150), (b) the number of bits they produced,
 where its own bits start, and (c) the few bits that share a byte with its first ones.  Each
 rank transforms and codes its stripe on its own GPU; the ranks exchange those O(N) scalars,
 shift their bits into place, stuff (0xFF -> 0xFF00 must come after the shift) and the pieces
-are concatenated.  Only the last stripe keeps the zero-padded partial byte.
+are copied device to device into one buffer at their byte offsets.  Only the last stripe keeps
+the zero-padded partial byte.
 """
 import numpy as np
 
@@ -58,8 +59,11 @@ class StripeJob:
     entropy(pred) -> nbits, stream_tail() -> int, stitch(bit_offset, head, is_last) -> (len, tail),
     scan(len) -> uint8 array.  jpeg_encoder_amd.Encoder provides these (front = front_host)."""
 
-    def __init__(self, backend, rank, world, rows, width, height, stride, v, bottom_up=True):
+    def __init__(self, backend, rank, world, rows, width, height, stride, v, bottom_up=True, stripe_ptr=None):
+        """stripe_ptr: device address of this rank's stripe rows when they are already resident on its GPU
+        (they must stay valid until code() has returned); rows may then be None."""
         self.backend, self.rank, self.world = backend, rank, world
+        self.stripe_ptr = stripe_ptr
         self.plan = plan_stripes(height, v, world)
         self.active = [k for k, (a, b) in enumerate(self.plan) if b > a]
         self.y0, self.y1 = self.plan[rank]
@@ -70,6 +74,9 @@ class StripeJob:
         """Colour conversion, subsampling, DCT and quantisation of the stripe -> its last DCs."""
         if self.empty:
             return (0, 0, 0)
+        if self.stripe_ptr is not None:
+            self.backend.stripe_device(self.stripe_ptr, self.width, self.y1 - self.y0, self.stride, self.bottom_up)
+            return tuple(int(x) for x in self.backend.last_dc())
         sub = stripe_rows(self.rows, self.height, self.y0, self.y1, self.bottom_up)
         front = getattr(self.backend, "front_host", None) or self.backend.front
         front(sub, self.width, self.y1 - self.y0, self.stride, self.bottom_up)
@@ -93,35 +100,134 @@ class StripeJob:
         n, _ = self.backend.stitch(offsets[self.rank], heads[self.rank], is_last)
         return self.backend.scan(n)
 
+    def place_on_device(self, all_codes):
+        """The same, leaving the piece in the backend's device memory: its length in bytes."""
+        if self.empty:
+            return 0
+        offsets, heads = stitch_plan([c[0] for c in all_codes], [c[1] for c in all_codes])
+        n, _ = self.backend.stitch(offsets[self.rank], heads[self.rank], self.rank == self.active[-1])
+        return n
 
-def encode_striped(backend, rows, width, height, stride, v, bottom_up=True, group=None, device=None):
-    """Runs the stripe of this rank (torch.distributed must be initialised; one process per GPU) and
-    returns the whole stuffed scan on rank 0, None elsewhere.  `rows` may hold the whole image or be
-    any object stripe_rows() can slice; only this rank's rows are touched.  `device` is where the
-    exchanged tensors live ("cuda:N" for the nccl backend, "cpu" for gloo)."""
-    import torch
-    import torch.distributed as dist
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    device = device or ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
 
-    def all_gather(values):
-        t = torch.tensor(values, dtype=torch.int64, device=device)
-        out = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(out, t, group=group)
+class ScalarExchange:
+    """The O(N) scalars that link neighbouring stripes travel through the host: an all_gather of a few int64 on
+    a gloo (CPU) group.  With an RCCL default group a gloo twin of it is created once."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        if group is None and dist.get_backend() != "gloo":
+            group = dist.new_group(backend="gloo")
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_gather(self, values):
+        import torch
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.group)
         return [tuple(int(x) for x in o.tolist()) for o in out]
 
-    job = StripeJob(backend, rank, world, rows, width, height, stride, v, bottom_up)
-    dcs = all_gather(list(job.transform()))
-    codes = all_gather(list(job.code(dcs)))
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+class DeviceGather:
+    """Where the stuffed pieces of all ranks meet: a device buffer owned by rank 0, which the other ranks open
+    through an inter-process memory handle and write their pieces into at their byte offsets with a
+    device-to-device copy (over xGMI between GPUs).  No collective moves scan bytes.  Kept across calls."""
+
+    def __init__(self, native, device):
+        self.N, self.device = native, device
+        self.L = native.lib()
+        self.own, self.own_cap = None, 0          # rank 0: the buffer
+        self.opened = {}                          # other ranks: handle bytes -> device address in this process
+
+    def handle_words(self, cap):
+        """Rank 0: (re)allocate for cap bytes and return the handle as 8 int64; others pass zeros."""
+        import ctypes as C
+        if cap > self.own_cap:
+            if self.own:
+                self.L.jpg_device_free(self.device, self.own)
+            cap = max(cap, 1 << 20)
+            self.own = self.L.jpg_device_alloc(self.device, cap)
+            if not self.own:
+                raise MemoryError("jpg_device_alloc(%d)" % cap)
+            self.own_cap = cap
+        h = (C.c_uint8 * self.N.IPC_HANDLE_BYTES)()
+        self.N.check(None, self.L.jpg_ipc_export(self.own, h))
+        return list(np.frombuffer(bytes(h), np.int64))
+
+    def address(self, words):
+        """The gather buffer's address in this process (rank 0: its own allocation)."""
+        import ctypes as C
+        if self.own:
+            return self.own
+        raw = np.array(words, np.int64).tobytes()
+        if raw not in self.opened:
+            h = (C.c_uint8 * self.N.IPC_HANDLE_BYTES).from_buffer_copy(raw)
+            p = C.c_void_p()
+            self.N.check(None, self.L.jpg_ipc_open(self.device, h, C.byref(p)))
+            self.opened[raw] = p.value
+        return self.opened[raw]
+
+    def read(self, n):
+        out = np.zeros(n, np.uint8)
+        if n:
+            self.N.check(None, self.L.jpg_device_to_host(self.device, out.ctypes.data, self.own, n))
+        return out
+
+    def close(self):
+        for p in self.opened.values():
+            self.L.jpg_ipc_close(p)
+        self.opened = {}
+        if self.own:
+            self.L.jpg_device_free(self.device, self.own)
+            self.own, self.own_cap = None, 0
+
+
+def encode_striped(backend, rows, width, height, stride, v, bottom_up=True, group=None, device=None, exchange=None,
+                   gather=None, fetch=True, stripe_ptr=None):
+    """Runs the stripe of this rank (torch.distributed must be initialised; one process per GPU) and returns the
+    whole stuffed scan on rank 0 (None elsewhere; with fetch=False rank 0 gets its length and the scan stays in
+    gather's device buffer).  `rows` may hold the whole image or be any object stripe_rows() can slice; only
+    this rank's rows are touched.  The scalars go through the host (ScalarExchange, gloo).  The pieces: a GPU
+    backend (jpeg_encoder_amd.Encoder) copies its piece device-to-device into rank 0's buffer (DeviceGather);
+    any other backend sends it to rank 0 point to point.  `device` is kept for callers of the earlier
+    interface and ignored."""
+    ex = exchange or ScalarExchange(group)
+    rank, world = ex.rank, ex.world
+    job = StripeJob(backend, rank, world, rows, width, height, stride, v, bottom_up, stripe_ptr)
+    dcs = ex.all_gather(job.transform())
+    codes = ex.all_gather(job.code(dcs))
+    on_device = hasattr(backend, "scan_copy_to_device")
+    if on_device:
+        from . import _native
+        gather = gather or DeviceGather(_native, backend.device)
+        n = job.place_on_device(codes)
+        bound = 2 * ((sum(c[0] for c in codes) + 7) // 8) + 16 * world       # every byte stuffed, at worst
+        words = gather.handle_words(bound) if rank == 0 else [0] * 8
+        got = ex.all_gather([n] + words)
+        lens = [g[0] for g in got]
+        base = gather.address(got[0][1:])
+        if n:
+            backend.scan_copy_to_device(base + sum(lens[:rank]), -1, n)
+        backend.sync()
+        ex.barrier()                                             # every piece has landed
+        if rank != 0:
+            return None
+        return gather.read(sum(lens)) if fetch else sum(lens)
+    import torch
     piece = job.place(codes)
-    lens = [x[0] for x in all_gather([int(piece.size)])]
-    # the pieces travel as one padded all_gather (point-to-point sends would do as well: N <= 8)
-    cap = max(max(lens), 1)
-    buf = torch.zeros(cap, dtype=torch.uint8, device=device)
-    if piece.size:
-        buf[:piece.size] = torch.from_numpy(piece).to(device)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf, group=group)
+    lens = [x[0] for x in ex.all_gather([int(piece.size)])]
     if rank != 0:
+        if piece.size:
+            ex.dist.send(torch.from_numpy(np.ascontiguousarray(piece)), dst=0, group=ex.group)
         return None
-    return np.concatenate([o[:n].cpu().numpy() for o, n in zip(out, lens)])
+    parts = [piece]
+    for k in range(1, world):
+        buf = torch.empty(lens[k], dtype=torch.uint8)
+        if lens[k]:
+            ex.dist.recv(buf, src=k, group=ex.group)
+        parts.append(buf.numpy())
+    return np.concatenate(parts)

@@ -101,3 +101,37 @@ def test_cli_stripes_and_batch(J, oracle, tmp_path):
         assert open(tmp_path / ("im%d.jpeg" % k), "rb").read() == want
     r = run(*args, "-o", str(tmp_path / "x.jpeg"))
     assert r.returncode == 2
+
+
+@pytest.mark.gpu
+def test_cli_strict_is_the_oracles_file_and_wide_stripes(J, oracle, tmp_path):
+    """--dct-algorithm real-dct-strict (not a value of the reference) writes the oracle's real-dct file byte for
+    byte; an image wide enough for the single coding kernel in stripes over two contexts does too."""
+    w, h = 1100, 210
+    rows = J.host.synth_bgr(w, h, seed=91)
+    bmp = str(tmp_path / "wide.bmp")
+    J.host.write_bmp(bmp, rows, w, h)
+    want = oracle.RefImage.from_bmp(bmp, (4, 2, 0), oracle.REAL).encode().file_bytes()
+    r = run("-i", bmp, "-d", "real-dct-strict")
+    assert r.returncode == 0, r.stderr
+    assert 'dct algorithm: "RealDct"' in r.stdout
+    assert open(tmp_path / "wide.jpeg", "rb").read() == want
+    r = run("-i", bmp, "-d", "real-dct-strict", "--fused", "-o", str(tmp_path / "f.jpeg"))
+    assert r.returncode == 0 and open(tmp_path / "f.jpeg", "rb").read() == want
+    r = run("-i", bmp, "-d", "real-dct-strict", "--stripes", "4", "--devices", "0,0", "-o", str(tmp_path / "s.jpeg"))
+    assert r.returncode == 0, r.stderr
+    assert open(tmp_path / "s.jpeg", "rb").read() == want
+    r = run("-i", bmp, "-d", "fast-dct")
+    assert r.returncode == 2 and "real-dct-strict" in r.stderr
+
+
+def test_cli_rejects_other_bitmap_formats(J, tmp_path):
+    import struct
+    rows = J.host.synth_bgr(8, 8, seed=1)
+    bmp = str(tmp_path / "x.bmp")
+    J.host.write_bmp(bmp, rows, 8, 8)
+    raw = bytearray(open(bmp, "rb").read())
+    struct.pack_into("<H", raw, 28, 32)
+    open(bmp, "wb").write(bytes(raw))
+    r = run("-i", bmp)
+    assert r.returncode == 101 and "Unsupported bitmap" in r.stderr

@@ -206,3 +206,56 @@ def test_fused_flat_image_many_tiles_per_segment(J, oracle, ratio):
     np.testing.assert_array_equal(scan, ref.stuffed_scan())
     bits, nbits = ref.bits()
     np.testing.assert_array_equal(enc.bits(nbits), bits)
+
+
+@pytest.mark.parametrize("ratio,algo,w,h,n", [
+    ((4, 2, 0), "bin-dct", 1032, 200, 3), ((4, 2, 2), "real-dct-strict", 1040, 120, 4), ((4, 4, 4), "bin-dct", 600, 70, 2),
+    ((4, 2, 0), "bin-dct", 300, 100, 3),                        # narrower than a tile: the kernel pair
+])
+def test_stripes_of_device_resident_rows(J, oracle, ratio, algo, w, h, n):
+    """Stripes whose rows already sit in device memory (jpg_stripe_device): coded by the single kernel straight
+    from the caller's rows, every step queued on all contexts before any is waited for (as one host thread drives
+    several GPUs), the pieces gathered device to device at their byte offsets."""
+    import ctypes as C
+    import torch
+    S = J.stripes
+    L = J._native.lib()
+    rows = J.host.synth_bgr(w, h, seed=23, noise_only=True)
+    stride = rows.shape[1]
+    _, v = J.get_downsampling_factor(ratio)
+    plan = S.plan_stripes(h, v, n)
+    dev = torch.from_numpy(rows).cuda()
+    torch.cuda.synchronize()
+    encs = [J.Encoder(ratio, algo) for _ in range(n)]
+    for e, (y0, y1) in zip(encs, plan):
+        e.stripe_device(dev.data_ptr() + (h - y1) * stride, w, y1 - y0, stride, True)
+        assert e.fused_coding() == (w >= tile_width(ratio))
+    for e in encs:
+        e.last_dc_async()
+    dcs = [e.last_dc() for e in encs]
+    for k, e in enumerate(encs):
+        e.entropy_stripe_async(dcs[k - 1] if k else (0, 0, 0))
+    codes = [e.entropy_stripe_finish() for e in encs]
+    for k, e in enumerate(encs):
+        assert e.stream_tail() == codes[k][1]
+    offsets, heads = S.stitch_plan([c[0] for c in codes], [c[1] for c in codes])
+    for k, e in enumerate(encs):
+        e.stitch_async(offsets[k], heads[k], k == n - 1)
+    lens = [e.stitch_finish()[0] for e in encs]
+    total = sum(lens)
+    buf = L.jpg_device_alloc(0, total)
+    assert buf
+    for k, e in enumerate(encs):
+        e.scan_copy_to_device(buf + sum(lens[:k]), 0, lens[k])
+    for e in encs:
+        e.sync()
+    got = np.zeros(total, np.uint8)
+    assert L.jpg_device_to_host(0, got.ctypes.data, buf, total) == 0
+    L.jpg_device_free(0, buf)
+    want = oracle.RefImage.from_bgr(rows, w, h, stride, ratio, oracle.BIN if algo == "bin-dct" else oracle.REAL).encode()
+    assert sum(c[0] for c in codes) == want.bits()[1]
+    np.testing.assert_array_equal(got, want.stuffed_scan())
+    for c in range(3):                                            # coefficients on request still work
+        first = oracle.RefImage.from_bgr(rows[h - plan[0][1]:], w, plan[0][1], stride, ratio,
+                                         oracle.BIN if algo == "bin-dct" else oracle.REAL).encode()
+        np.testing.assert_array_equal(encs[0].coeffs(c), first.coeffs(c))
