@@ -661,7 +661,10 @@ static int queue_coding(jpg_ctx *c, const int16_t *pred) {
     if (code_from_rows(c)) {
         // no coefficients were asked for so far: one kernel from the rows to the coded tiles
         if (int e = prepare_slot(c, true)) return e;
-        HIP_TRY(c, launch_coded(c->g, c->algo, c->d_src, nullptr, 1, pred ? pred : ZERO_PRED, S(c).eb, c->stream));
+        if (int e = launch_timed(c, 1, [&](hipEvent_t e0, hipEvent_t e1) {
+                return launch_coded(c->g, c->algo, c->d_src, nullptr, 1, pred ? pred : ZERO_PRED, S(c).eb, c->stream, e0, e1);
+            }))
+            return e;
     } else {
         if (int e = need_coef(c)) return e;
         if (int e = queue_entropy(c, pred)) return e;

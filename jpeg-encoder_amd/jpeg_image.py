@@ -165,7 +165,7 @@ class Encoder:
     def encode_batch_device_async(self, dev_ptrs, width, height, stride, bottom_up=True):
         """Queue one launch set for len(dev_ptrs) equally sized device-resident images."""
         n = len(dev_ptrs)
-        arr = (C.c_void_p * n)(*dev_ptrs)
+        arr = dev_ptrs if isinstance(dev_ptrs, C.Array) else (C.c_void_p * n)(*dev_ptrs)   # (a prepared array is used as is)
         self.width, self.height = width, height
         self._ck(self._L.jpg_encode_batch_device_async(self._ctx, arr, n, width, height, stride, int(bottom_up)))
 

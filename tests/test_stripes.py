@@ -3,6 +3,7 @@ arithmetic, a lock-step simulation of N ranks, and two real processes over gloo.
 results come from the oracle (tests/stripe_fakes.py); the GPU backend is tested in
 test_gpu_parity.py."""
 import os
+import time
 import sys
 
 import numpy as np
@@ -94,12 +95,23 @@ def _worker(rank, world, port, tmp):
         plan = J.stripes.plan_stripes(h, 2, world)
         be = OracleStripe(refcpu, rows, w, h, stride, ratio, refcpu.BIN, *plan[rank])
         scan = J.stripes.encode_striped(be, rows, w, h, stride, 2, device="cpu")
+        # the same with the scalars exchanged through shared host memory instead of gloo
+        shm = J.stripes.ShmExchange.from_group()
+        for k in range(300):                              # ranks out of step: the records are double-buffered
+            got = shm.all_gather([rank * 1000 + k, k])
+            assert got == [(r * 1000 + k, k) for r in range(world)]
+            if (k + rank) % 7 == 0:
+                time.sleep(0.0005)
+        scan2 = J.stripes.encode_striped(be, rows, w, h, stride, 2, exchange=shm)
+        shm.close()
         if rank == 0:
             want = refcpu.RefImage.from_bgr(rows, w, h, stride, ratio, refcpu.BIN).encode().stuffed_scan()
             assert np.array_equal(scan, want)
+            assert np.array_equal(scan2, want)
+            assert not os.path.exists(shm.path)
             open(os.path.join(tmp, "ok"), "w").write("%d" % len(scan))
         else:
-            assert scan is None
+            assert scan is None and scan2 is None
     finally:
         dist.destroy_process_group()
 
