@@ -168,11 +168,7 @@ extern "C" int jpg_create(jpg_ctx **out, int device, int dct_algo, int ra, int r
     if (!out) return JPG_ERR_BAD_ARG;
     *out = nullptr;
     int h, v;
-    // src/jpeg/sampling.rs:6-22
-    if (ra == 4 && rb == 4 && rc == 4) { h = 1; v = 1; }
-    else if (ra == 4 && rb == 2 && rc == 0) { h = 2; v = 2; }
-    else if (ra == 4 && rb == 2 && rc == 2) { h = 2; v = 1; }
-    else return JPG_ERR_INVALID_RATIO;
+    if (!ratio_factors(ra, rb, rc, h, v)) return JPG_ERR_INVALID_RATIO;
     if (dct_algo != JPG_DCT_REAL && dct_algo != JPG_DCT_BIN && dct_algo != JPG_DCT_REAL_STRICT) return JPG_ERR_BAD_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
@@ -250,11 +246,20 @@ extern "C" int jpg_sync(jpg_ctx *c) {
     return sync_all(c);
 }
 
-// JpegImage::new's dimension arithmetic (src/jpeg/jpeg_image.rs:36-56)
-static int set_geometry(jpg_ctx *c, int32_t W, int32_t H, uint32_t stride, int bottom_up) {
+namespace jpg {
+bool ratio_factors(int ra, int rb, int rc, int &h, int &v) {
+    // src/jpeg/sampling.rs:6-22
+    if (ra == 4 && rb == 4 && rc == 4) { h = 1; v = 1; }
+    else if (ra == 4 && rb == 2 && rc == 0) { h = 2; v = 2; }
+    else if (ra == 4 && rb == 2 && rc == 2) { h = 2; v = 1; }
+    else return false;
+    return true;
+}
+
+int make_geom(Geom &g, int32_t W, int32_t H, uint32_t stride, int bottom_up, int h, int v) {
     if (W <= 0 || H <= 0 || (uint64_t)stride < (uint64_t)3 * (uint64_t)W) return JPG_ERR_BAD_ARG;
-    Geom g{};
-    g.W = W; g.H = H; g.h = c->h; g.v = c->v;
+    g = Geom{};
+    g.W = W; g.H = H; g.h = h; g.v = v;
     g.Wp = round_up(W, 8 * g.h); g.Hp = round_up(H, 8 * g.v);
     g.Wc = round_up(W / g.h, 8); g.Hc = round_up(H / g.v, 8);
     if (g.Wc != g.Wp / g.h || g.Hc != g.Hp / g.v) return JPG_ERR_UNSUPPORTED_DIMS;
@@ -262,6 +267,13 @@ static int set_geometry(jpg_ctx *c, int32_t W, int32_t H, uint32_t stride, int b
     g.nb = g.h * g.v + 2;
     g.stride = stride; g.bottom_up = bottom_up ? 1 : 0;
     g.nblocks = (long long)g.mcux * g.mcuy * g.nb;
+    return JPG_OK;
+}
+}  // namespace jpg
+
+static int set_geometry(jpg_ctx *c, int32_t W, int32_t H, uint32_t stride, int bottom_up) {
+    Geom g{};
+    if (int e = make_geom(g, W, H, stride, bottom_up, c->h, c->v)) return e;
     c->g = g;
     c->nimg = 1;
     c->stage = ST_NONE; c->have_planes = false; c->down_done = false; c->coef_valid = false;
@@ -272,12 +284,6 @@ static int set_geometry(jpg_ctx *c, int32_t W, int32_t H, uint32_t stride, int b
 static int ensure_coef(jpg_ctx *c) {
     const size_t nblk = (size_t)c->g.nblocks * (size_t)(c->nimg > 0 ? c->nimg : 1);
     return grow(c, c->d_coef, c->coef_cap, nblk * 64);
-}
-
-// worst case of the unstuffed stream: every block at its maximum coded size
-static size_t worst_bits_bytes(size_t nblk) {
-    const size_t b = (nblk * MAX_BLOCK_BITS + 7) / 8 + 64;
-    return (b + 15) / 16 * 16;
 }
 
 template <class T>
@@ -301,9 +307,8 @@ static int ensure_entropy(jpg_ctx *c, bool coded) {
     const size_t slot_words = coded ? (size_t)coded_slot_words(c->g) : (size_t)CHUNK_STRIDE_WORDS;
     if ((nchunks + 63) / 64 > (size_t)MAX_GROUPS) return JPG_ERR_TOO_LARGE;
     const size_t cstride = (nchunks + 63) / 64 * 64;
-    const size_t bits_bytes = worst_bits_bytes(nblk);
-    const size_t scan_stride = (2 * bits_bytes + 16 + 255) / 256 * 256;
-    const size_t nseg = bits_bytes / STUFF_SEG + 2;
+    const size_t scan_stride = worst_scan_bytes(nblk);
+    const size_t nseg = worst_segments(nblk);
     sl.eb.nimg = (int)nimg;
     sl.eb.nchunks = (long long)nchunks;
     sl.eb.cstride = (long long)cstride;

@@ -118,4 +118,20 @@ hipError_t launch_tail(const EntropyBufs &b, hipStream_t s);
 // most images one launch of the stream kernels can take
 int max_batch_images();
 
+// JpegImage::new's dimension arithmetic (src/jpeg/jpeg_image.rs:36-56) for chroma factors (h, v): fills g and
+// returns a jpg_status (bad sizes, or the sizes at which the reference skews its chroma plane)
+int make_geom(Geom &g, int32_t W, int32_t H, uint32_t stride, int bottom_up, int h, int v);
+// (4,4,4) -> (1,1), (4,2,0) -> (2,2), (4,2,2) -> (2,1) (src/jpeg/sampling.rs:6-22); false for any other ratio
+bool ratio_factors(int ra, int rb, int rc, int &h, int &v);
+
+// worst case of the unstuffed stream in bytes: every block at its maximum coded size
+inline size_t worst_bits_bytes(size_t nblk) {
+    const size_t b = (nblk * MAX_BLOCK_BITS + 7) / 8 + 64;
+    return (b + 15) / 16 * 16;
+}
+// bytes a stuffed scan can take at worst (every byte 0xFF), rounded up to 256
+inline size_t worst_scan_bytes(size_t nblk) { return (2 * worst_bits_bytes(nblk) + 16 + 255) / 256 * 256; }
+// stuffing segments an image of nblk blocks can have
+inline size_t worst_segments(size_t nblk) { return worst_bits_bytes(nblk) / STUFF_SEG + 2; }
+
 }  // namespace jpg
