@@ -231,6 +231,46 @@ int jpg_ipc_export(const void *dev_ptr, uint8_t handle[JPG_IPC_HANDLE_BYTES]);
 int jpg_ipc_open(int device, const uint8_t handle[JPG_IPC_HANDLE_BYTES], void **dev_ptr);
 int jpg_ipc_close(void *dev_ptr);
 
+/* ---- an encode that allocates nothing ---------------------------------------
+ *
+ * No counterpart in the reference.  For callers that cannot allocate device memory while they run: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  jpg_encode_device_static is
+ * jpg_encode_device_async + jpg_finish without a context: the same two kernels (rows -> coded tiles, coded
+ * tiles -> stuffed scan) are queued on the caller's stream, and the working memory a context would allocate
+ * (coded tiles, their lengths, the stuffing kernel's hand-off words and counters, the status record) is a
+ * fixed array of JPG_STATIC_SCRATCH_BYTES inside the library's code object, one copy per GPU, held until the
+ * process ends.  The call makes no hipMalloc/hipFree and creates no stream or event; it only queues a memset
+ * and two kernels and returns without waiting.
+ *
+ *  - dev_pixels: device-resident BMP rows, 4-byte aligned base and stride; width at least one tile of the
+ *    coding kernel (512 pixels, 1024 at 4:2:2), else JPG_ERR_BAD_ARG.
+ *  - limit: images whose working memory exceeds the array are refused with JPG_ERR_TOO_LARGE.  Fits e.g.
+ *    1920x1080 at every ratio and 2048x2048 at 4:2:0.
+ *  - dev_scan / scan_cap: the caller's output buffer in device memory; scan_cap must be at least
+ *    jpg_static_scan_capacity(width, height, ratio) (the worst case: every byte stuffed), else JPG_ERR_CAPACITY.
+ *  - dev_result: 32 bytes the device can write (device memory or page-locked host memory); filled by the last
+ *    kernel.  After the stream has been waited for, jpg_static_status() of a host copy gives JPG_OK or the
+ *    status a kernel raised (the reference's range panics), and nbits / scan_bytes the sizes.
+ *  - stream: a hipStream_t of `device` (NULL = the default stream).
+ *  - all calls on one GPU share that GPU's array: two calls whose kernels may overlap on one GPU (different
+ *    streams, or different processes' contexts are fine -- each process has its own copy) race.  Queue them
+ *    on one stream, or order them with events.
+ * jpg_static_init(device) looks up the array's address on that device ahead of the first call (otherwise the
+ * first call on a device does it). */
+#define JPG_STATIC_SCRATCH_BYTES (24u << 20)
+typedef struct jpg_static_result {
+    uint64_t nbits;      /* bits of the unstuffed stream */
+    uint64_t scan_bytes; /* bytes written to dev_scan */
+    int32_t error;       /* raw status word: decode with jpg_static_status */
+    uint32_t reserved[3];
+} jpg_static_result;
+int jpg_static_init(int device);
+size_t jpg_static_scan_capacity(int32_t width, int32_t height, int ra, int rb, int rc);
+int jpg_encode_device_static(int device, int dct_algo, int ra, int rb, int rc, const uint8_t *dev_pixels, int32_t width,
+                             int32_t height, uint32_t row_stride, int bottom_up, uint8_t *dev_scan, size_t scan_cap,
+                             jpg_static_result *dev_result, void *stream);
+int jpg_static_status(const jpg_static_result *host_copy);
+
 /* ---- results ------------------------------------------------------------ */
 
 /* device pointers of the current results (valid until the next call that

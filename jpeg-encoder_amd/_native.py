@@ -25,7 +25,14 @@ SYMBOLS = [
     "jpg_front_samples", "jpg_stripe_device", "jpg_stripe_host_async", "jpg_last_dc_async", "jpg_entropy_stripe_async", "jpg_entropy_stripe_finish",
     "jpg_stitch_async", "jpg_stitch_finish", "jpg_scan_copy_to_device", "jpg_device_alloc", "jpg_device_free",
     "jpg_device_to_host", "jpg_ipc_export", "jpg_ipc_open", "jpg_ipc_close",
+    "jpg_static_init", "jpg_static_scan_capacity", "jpg_encode_device_static", "jpg_static_status",
 ]
+STATIC_SCRATCH_BYTES = 24 << 20
+
+
+class StaticResult(C.Structure):
+    _fields_ = [("nbits", C.c_uint64), ("scan_bytes", C.c_uint64), ("error", C.c_int32), ("reserved", C.c_uint32 * 3)]
+
 IPC_HANDLE_BYTES = 64
 
 
@@ -132,6 +139,12 @@ def lib():
     L.jpg_ipc_export.argtypes = [vp, C.POINTER(C.c_uint8)]
     L.jpg_ipc_open.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.POINTER(vp)]
     L.jpg_ipc_close.argtypes = [vp]
+    L.jpg_static_init.argtypes = [C.c_int]
+    L.jpg_static_scan_capacity.argtypes = [i32, i32, C.c_int, C.c_int, C.c_int]
+    L.jpg_static_scan_capacity.restype = C.c_size_t
+    L.jpg_encode_device_static.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i32, i32, u32, C.c_int, vp,
+                                           C.c_size_t, vp, vp]
+    L.jpg_static_status.argtypes = [C.POINTER(StaticResult)]
     _lib = L
     return L
 
