@@ -166,6 +166,15 @@ int jpg_finish_next(jpg_ctx *ctx, uint64_t *nbits, size_t *stuffed_len);
  * (library-allocated pinned memory; release with jpg_free) */
 int jpg_encode_scan(jpg_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t height,
                     uint32_t row_stride, int bottom_up, uint8_t **stuffed, size_t *len);
+/* The same in two steps, so that the host can do its own work (emit the file header: generate_file,
+ * src/jpeg/file.rs:105-133, writes 623 bytes before the scan) while the device works.  _begin queues the encode
+ * and returns: where the single coding kernel applies, the rows are copied and coded band by band (a band of MCU
+ * rows is coded while the following bands are still on their way to the device), and the output buffer is
+ * allocated meanwhile.  `pixels` must stay valid and unchanged until _end returns.  _end waits, copies the
+ * stuffed scan to the host and hands the buffer over (jpg_free).  One begun encode per context at a time. */
+int jpg_encode_scan_begin(jpg_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t height, uint32_t row_stride,
+                          int bottom_up);
+int jpg_encode_scan_end(jpg_ctx *ctx, uint8_t **stuffed, size_t *len);
 void jpg_free(void *p);
 
 /* ---- MCU-row stripes of one large image (no counterpart in the reference,

@@ -25,6 +25,7 @@ SYMBOLS = [
     "jpg_front_samples", "jpg_stripe_device", "jpg_stripe_host_async", "jpg_last_dc_async", "jpg_entropy_stripe_async", "jpg_entropy_stripe_finish",
     "jpg_stitch_async", "jpg_stitch_finish", "jpg_scan_copy_to_device", "jpg_device_alloc", "jpg_device_free",
     "jpg_device_to_host", "jpg_ipc_export", "jpg_ipc_open", "jpg_ipc_close",
+    "jpg_encode_scan_begin", "jpg_encode_scan_end",
     "jpg_static_init", "jpg_static_scan_capacity", "jpg_encode_device_static", "jpg_static_status",
 ]
 STATIC_SCRATCH_BYTES = 24 << 20
@@ -139,6 +140,8 @@ def lib():
     L.jpg_ipc_export.argtypes = [vp, C.POINTER(C.c_uint8)]
     L.jpg_ipc_open.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.POINTER(vp)]
     L.jpg_ipc_close.argtypes = [vp]
+    L.jpg_encode_scan_begin.argtypes = [vp, vp, i32, i32, u32, C.c_int]
+    L.jpg_encode_scan_end.argtypes = [vp, C.POINTER(vp), szp]
     L.jpg_static_init.argtypes = [C.c_int]
     L.jpg_static_scan_capacity.argtypes = [i32, i32, C.c_int, C.c_int, C.c_int]
     L.jpg_static_scan_capacity.restype = C.c_size_t

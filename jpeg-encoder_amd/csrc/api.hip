@@ -56,9 +56,20 @@ struct jpg_ctx {
     int fifo[NSLOT] = {};        // slots of queued fused encodes that jpg_finish_next has not handed out yet
     int npend = 0;
     hipStream_t stream_b = nullptr;
+    // whole encodes of host rows go band by band: the rows of a band travel on stream_c while the bands before it
+    // are coded on `stream`
+    hipStream_t stream_c = nullptr;
+    static constexpr int MAX_BANDS = 16;
+    hipEvent_t band_ev[MAX_BANDS] = {};
+    hipEvent_t src_free = nullptr;   // everything queued on `stream` that reads d_src_own has finished
+    size_t last_scan_len = 0;        // size of the previous stuffed scan: the first guess for the next output buffer
+    uint8_t *scan_host = nullptr;    // output buffer of a begun jpg_encode_scan (page-locked), handed to the caller by _end
+    size_t scan_host_cap = 0;
+    bool scan_begun = false;
     // two page-locked bounce buffers for rows that arrive in pageable host memory
     uint8_t *h_bounce[2] = {nullptr, nullptr};
     hipEvent_t bounce_done[2] = {nullptr, nullptr};
+    bool bounce_used[2] = {false, false};   // bounce_done[k] has been recorded
     // optional timing of the front kernel: a ring of event pairs, harvested by jpg_front_time
     int timing = 0;             // 0 = off, n = bracket every n-th front launch
     uint64_t t_seen = 0;
@@ -138,6 +149,7 @@ static int use_device(jpg_ctx *c, DeviceGuard &g) {
 }
 
 static int sync_all(jpg_ctx *c) {
+    if (c->stream_c) HIP_TRY(c, hipStreamSynchronize(c->stream_c));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->stream_b) HIP_TRY(c, hipStreamSynchronize(c->stream_b));
     return JPG_OK;
@@ -232,6 +244,12 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
         if (c->bounce_done[k]) (void)hipEventDestroy(c->bounce_done[k]);
     }
     if (c->h_dc) (void)hipHostFree(c->h_dc);
+    if (c->scan_host) (void)hipHostFree(c->scan_host);
+    for (hipEvent_t e : c->band_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->src_free) (void)hipEventDestroy(c->src_free);
+    if (c->stream_c) { (void)hipStreamSynchronize(c->stream_c); (void)hipStreamDestroy(c->stream_c); }
+
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     delete c;
@@ -372,18 +390,19 @@ static bool is_pinned_host(const void *p) {
 // pageable rows -> device, through the two bounce buffers: while one chunk travels by DMA the
 // next is packed by the CPU (a pageable hipMemcpy2D runs at a fraction of the link speed)
 static int copy_rows_staged(jpg_ctx *c, uint8_t *dst, uint32_t pitch, const uint8_t *src, uint32_t stride,
-                            size_t row_bytes, int32_t rows) {
+                            size_t row_bytes, int32_t rows, hipStream_t st) {
     for (int k = 0; k < 2; k++) {
         if (!c->h_bounce[k]) HIP_TRY(c, hipHostMalloc((void **)&c->h_bounce[k], BOUNCE_BYTES, hipHostMallocDefault));
         if (!c->bounce_done[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->bounce_done[k], hipEventDisableTiming));
     }
     const int32_t per = (int32_t)(BOUNCE_BYTES / pitch);
     if (per < 1) {   // a row longer than a bounce buffer: let the runtime stage it
-        HIP_TRY(c, hipMemcpy2DAsync(dst, pitch, src, stride, row_bytes, (size_t)rows, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpy2DAsync(dst, pitch, src, stride, row_bytes, (size_t)rows, hipMemcpyHostToDevice, st));
         return JPG_OK;
     }
     int k = 0;
-    bool used[2] = {false, false};
+    // (a buffer may still be travelling for an earlier call: its event, once recorded, is waited for)
+    bool used[2] = {c->bounce_used[0], c->bounce_used[1]};
     for (int32_t r0 = 0; r0 < rows; r0 += per, k ^= 1) {
         const int32_t n = rows - r0 < per ? rows - r0 : per;
         if (used[k]) HIP_TRY(c, hipEventSynchronize(c->bounce_done[k]));
@@ -393,9 +412,10 @@ static int copy_rows_staged(jpg_ctx *c, uint8_t *dst, uint32_t pitch, const uint
         } else {
             for (int32_t r = 0; r < n; r++) memcpy(b + (size_t)r * pitch, src + (size_t)(r0 + r) * stride, row_bytes);
         }
-        HIP_TRY(c, hipMemcpyAsync(dst + (size_t)r0 * pitch, b, (size_t)n * pitch, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipEventRecord(c->bounce_done[k], c->stream));
+        HIP_TRY(c, hipMemcpyAsync(dst + (size_t)r0 * pitch, b, (size_t)n * pitch, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipEventRecord(c->bounce_done[k], st));
         used[k] = true;
+        c->bounce_used[k] = true;
     }
     return JPG_OK;
 }
@@ -412,7 +432,7 @@ static int stage_input(jpg_ctx *c, const uint8_t *pixels, bool on_host) {
     const uint32_t pitch = (g.stride & 3) == 0 ? g.stride : (uint32_t)round_up(3 * g.W, 4);
     if (int e = grow(c, c->d_src_own, c->src_cap, (size_t)pitch * g.H + 16)) return e;
     if (on_host && !is_pinned_host(pixels)) {
-        if (int e = copy_rows_staged(c, c->d_src_own, pitch, pixels, g.stride, (size_t)3 * g.W, g.H)) return e;
+        if (int e = copy_rows_staged(c, c->d_src_own, pitch, pixels, g.stride, (size_t)3 * g.W, g.H, c->stream)) return e;
     } else {
         HIP_TRY(c, hipMemcpy2DAsync(c->d_src_own, pitch, pixels, g.stride, (size_t)3 * g.W, (size_t)g.H,
                                     on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
@@ -1084,26 +1104,149 @@ extern "C" int jpg_finish_next(jpg_ctx *c, uint64_t *nbits, size_t *stuffed_len)
     return report(c, k, nbits, stuffed_len);
 }
 
+// A whole encode of rows in host memory, band by band: the rows of a band of MCU rows are copied on stream_c
+// and the band is coded on `stream` as soon as they have landed, while the following bands are still
+// travelling (a tile needs its own rows and the MCU before it, which lies in its own band or the one above).
+// Geometry set; only where the single coding kernel applies.
+static int queue_encode_host_banded(jpg_ctx *c, const uint8_t *pixels, uint32_t host_stride) {
+    Geom &g = c->g;
+    const uint32_t pitch = (host_stride & 3) == 0 ? host_stride : (uint32_t)round_up(3 * g.W, 4);
+    if (int e = grow(c, c->d_src_own, c->src_cap, (size_t)pitch * g.H + 16)) return e;
+    g.stride = pitch;
+    c->d_src = c->d_src_own;
+    if (!c->stream_c) HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+    if (!c->src_free) HIP_TRY(c, hipEventCreateWithFlags(&c->src_free, hipEventDisableTiming));
+    const bool pinned = is_pinned_host(pixels);
+    c->cur = (c->cur + 1) % jpg_ctx::NSLOT;
+    if (int e = prepare_slot(c, true)) return e;
+    // the copies overwrite the context's rows: not before the kernels queued earlier have read them
+    HIP_TRY(c, hipEventRecord(c->src_free, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream_c, c->src_free, 0));
+    const int mcu_h = 8 * g.v;
+    // A few bands are enough: all but the last band's coding is hidden behind the copies that follow, and every
+    // band costs an event, a wait and a launch (JPG_BANDS overrides, for experiments).  Measured on 7680x4320
+    // rows in page-locked memory: 2.02-2.05 ms with 1, 2, 4 or 8 bands and with one or two copy streams -- the
+    // copy itself (99.5 MB at about 50 GB/s) is all of it, the 45 us of coding disappear behind it either way.
+    // Rows in pageable memory are packed into the staging buffers by the CPU, which is what their time is made
+    // of (3.7 ms for the same image): cutting them into bands only adds waits between the chunks (4.1-4.4 ms).
+    int nb = !pinned ? 1 : (g.mcuy / 32 < 4 ? g.mcuy / 32 : 4);
+    if (const char *ev = getenv("JPG_BANDS")) nb = atoi(ev);
+    if (nb < 1) nb = 1;
+    if (nb > jpg_ctx::MAX_BANDS) nb = jpg_ctx::MAX_BANDS;
+    const int per = (g.mcuy + nb - 1) / nb;
+    for (int b = 0, r0 = 0; r0 < g.mcuy; b++, r0 += per) {
+        const int rows = r0 + per <= g.mcuy ? per : g.mcuy - r0;
+        const int y0 = r0 * mcu_h, y1 = (r0 + rows) * mcu_h < g.H ? (r0 + rows) * mcu_h : g.H;   // image rows of the band
+        const int f0 = g.bottom_up ? g.H - y1 : y0, n = y1 - y0;                                // ... in the caller's array
+        const hipStream_t cs = c->stream_c;
+        if (n > 0) {
+            uint8_t *dst = c->d_src_own + (size_t)f0 * pitch;
+            const uint8_t *src = pixels + (size_t)f0 * host_stride;
+            if (pinned && pitch == host_stride) {   // whole rows, one after the other: a plain copy
+                HIP_TRY(c, hipMemcpyAsync(dst, src, (size_t)(n - 1) * pitch + (size_t)3 * g.W, hipMemcpyHostToDevice, cs));
+            } else if (pinned) {
+                HIP_TRY(c, hipMemcpy2DAsync(dst, pitch, src, host_stride, (size_t)3 * g.W, (size_t)n, hipMemcpyHostToDevice,
+                                            cs));
+            } else if (int e = copy_rows_staged(c, dst, pitch, src, host_stride, (size_t)3 * g.W, n, cs)) {
+                return e;
+            }
+        }
+        hipEvent_t &ev = c->band_ev[b];
+        if (!ev) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(ev, cs));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, ev, 0));
+        if (int e = launch_timed(c, 1, [&](hipEvent_t e0, hipEvent_t e1) {
+                return launch_coded(g, c->algo, c->d_src, nullptr, 1, ZERO_PRED, S(c).eb, c->stream, e0, e1, r0, rows);
+            }))
+            return e;
+    }
+    c->coef_valid = false;
+    c->stage = ST_COEF;
+    if (int e = queue_stuff(c, 0, 0, 1, c->stream_b)) return e;
+    if (c->npend == jpg_ctx::NSLOT) {
+        for (int k = 1; k < c->npend; k++) c->fifo[k - 1] = c->fifo[k];
+        c->npend--;
+    }
+    c->fifo[c->npend++] = c->cur;
+    return JPG_OK;
+}
+
+extern "C" int jpg_encode_scan_begin(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride, int bottom_up) {
+    if (!c || !pixels) return JPG_ERR_BAD_ARG;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
+    c->scan_begun = false;
+    if (!c->two_kernels && coded_supported(c->g)) {
+        if (int e = queue_encode_host_banded(c, pixels, stride)) return e;
+    } else {
+        if (int e = stage_input(c, pixels, true)) return e;
+        if (int e = queue_encode(c)) return e;
+    }
+    // The output buffer is page-locked memory the caller will own; pinning pages takes a while, so it is
+    // allocated now, while the device works, for the size of the previous scan plus a margin (first call: a
+    // quarter byte per pixel); _end allocates again in the rare case that it is too small.
+    const size_t guess = c->last_scan_len ? c->last_scan_len + c->last_scan_len / 4 + 4096 : (size_t)W * H / 4 + 4096;
+    if (c->scan_host && c->scan_host_cap < guess) {
+        (void)hipHostFree(c->scan_host);
+        c->scan_host = nullptr;
+        c->scan_host_cap = 0;
+    }
+    if (!c->scan_host) {
+        void *host = nullptr;
+        if (hipHostMalloc(&host, guess, hipHostMallocDefault) == hipSuccess) {
+            c->scan_host = static_cast<uint8_t *>(host);
+            c->scan_host_cap = guess;
+        } else {
+            (void)hipGetLastError();   // _end tries again with the exact size
+        }
+    }
+    c->scan_begun = true;
+    return JPG_OK;
+}
+
+extern "C" int jpg_encode_scan_end(jpg_ctx *c, uint8_t **stuffed, size_t *len) {
+    if (!c || !stuffed || !len) return JPG_ERR_BAD_ARG;
+    *stuffed = nullptr; *len = 0;
+    if (!c->scan_begun) return JPG_ERR_STATE;
+    c->scan_begun = false;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    // (the caller's rows have all been copied when the last band's kernel has run: jpg_finish waits for more)
+    if (int e = jpg_finish(c, nullptr, nullptr)) return e;
+    const jpg_ctx::Slot &sl = V(c);
+    c->last_scan_len = sl.scan_len;
+    if (c->scan_host && c->scan_host_cap < sl.scan_len) {
+        (void)hipHostFree(c->scan_host);
+        c->scan_host = nullptr;
+        c->scan_host_cap = 0;
+    }
+    if (!c->scan_host) {
+        void *host = nullptr;
+        hipError_t he = hipHostMalloc(&host, sl.scan_len ? sl.scan_len : 1, hipHostMallocDefault);
+        if (he != hipSuccess) { c->last_hip = (int)he; (void)hipGetLastError(); return JPG_ERR_NOMEM; }
+        c->scan_host = static_cast<uint8_t *>(host);
+        c->scan_host_cap = sl.scan_len ? sl.scan_len : 1;
+    }
+    hipError_t he = hipSuccess;
+    if (sl.scan_len) {
+        he = hipMemcpyAsync(c->scan_host, sl.eb.scan, sl.scan_len, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    }
+    if (he != hipSuccess) { c->last_hip = (int)he; (void)hipGetLastError(); return JPG_ERR_HIP; }
+    *stuffed = c->scan_host;       // the caller's from here on (jpg_free)
+    *len = sl.scan_len;
+    c->scan_host = nullptr;
+    c->scan_host_cap = 0;
+    return JPG_OK;
+}
+
 extern "C" int jpg_encode_scan(jpg_ctx *c, const uint8_t *pixels, int32_t W, int32_t H, uint32_t stride, int bottom_up,
                                uint8_t **stuffed, size_t *len) {
     if (!c || !pixels || !stuffed || !len) return JPG_ERR_BAD_ARG;
     *stuffed = nullptr; *len = 0;
-    DeviceGuard dg;
-    if (int e = use_device(c, dg)) return e;
-    if (int e = set_geometry(c, W, H, stride, bottom_up)) return e;
-    if (int e = stage_input(c, pixels, true)) return e;
-    if (int e = queue_encode(c)) return e;
-    if (int e = jpg_finish(c, nullptr, nullptr)) return e;
-    const jpg_ctx::Slot &sl = V(c);
-    void *host = nullptr;
-    hipError_t he = hipHostMalloc(&host, sl.scan_len ? sl.scan_len : 1, hipHostMallocDefault);
-    if (he != hipSuccess) { c->last_hip = (int)he; (void)hipGetLastError(); return JPG_ERR_NOMEM; }
-    he = hipMemcpyAsync(host, sl.eb.scan, sl.scan_len, hipMemcpyDeviceToHost, c->stream);
-    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
-    if (he != hipSuccess) { (void)hipHostFree(host); c->last_hip = (int)he; (void)hipGetLastError(); return JPG_ERR_HIP; }
-    *stuffed = static_cast<uint8_t *>(host);
-    *len = sl.scan_len;
-    return JPG_OK;
+    if (int e = jpg_encode_scan_begin(c, pixels, W, H, stride, bottom_up)) return e;
+    return jpg_encode_scan_end(c, stuffed, len);
 }
 
 extern "C" void *jpg_host_alloc(size_t bytes) {

@@ -37,6 +37,7 @@ struct CodedArgs {
     // then one scalar load away at the start of the kernel instead of two dependent ones.
     const uint8_t *src[MAX_LAUNCH_IMAGES];
     Geom g;
+    int mcu_row0;                 // first MCU row of this launch (0 unless the image is coded band by band)
     int16_t pred[3];              // DC predictors the first MCU of every image starts from
     uint32_t epoch;               // tags errors (see raise_error)
     long long cstride;            // tile slots per image in clen / sparse
@@ -63,8 +64,9 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
     uint8_t *sCr = sCb + 8 * C::CW;
     const Geom &g = a.g;
 
-    // grid: x = tile column, y = MCU row, z = image of a batch (no divisions to find the tile)
-    const int tile_x = blockIdx.x, tile_y = blockIdx.y, img = blockIdx.z;
+    // grid: x = tile column, y = MCU row (counted from the first row of the launch: a launch may cover a band of
+    // rows, the rows above it being coded by earlier launches), z = image of a batch; no divisions to find the tile
+    const int tile_x = blockIdx.x, tile_y = blockIdx.y + a.mcu_row0, img = blockIdx.z;
     const int tile = tile_y * (int)gridDim.x + tile_x;       // number of the tile in the scan of its image
     const uint8_t *src = a.src[img];
     const int mcu0 = tile_x * C::MCUS;                        // first MCU column of the tile
@@ -222,14 +224,16 @@ hipError_t launch_last_dc_pixels(const Geom &g, int algo, const uint8_t *src, in
 }
 
 template <int HS, int VS>
-static hipError_t launch_coded_hv(const CodedArgs &a, int algo, int nimg, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+static hipError_t launch_coded_hv(const CodedArgs &a, int algo, int nimg, int mcu_rows, hipStream_t s, hipEvent_t e0,
+                                  hipEvent_t e1) {
     using C = TileCfg<HS, VS>;
     const int tiles_x = (a.g.mcux + C::MCUS - 1) / C::MCUS;
     const long long tiles = (long long)tiles_x * a.g.mcuy;
     if (tiles <= 0 || tiles * nimg > 0x7fffffffLL || tiles > a.cstride || a.slot_words != coded_slot_words(a.g))
         return hipErrorInvalidValue;
     if (a.g.mcuy > 65535 || nimg > 65535) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)tiles_x, (unsigned)a.g.mcuy, (unsigned)nimg), block(THREADS);
+    if (mcu_rows < 1 || a.mcu_row0 < 0 || a.mcu_row0 + mcu_rows > a.g.mcuy) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)tiles_x, (unsigned)mcu_rows, (unsigned)nimg), block(THREADS);
     switch (algo) {
         case ALGO_REAL: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, a); break;
         case ALGO_BIN: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, a); break;
@@ -253,19 +257,21 @@ int coded_slot_words(const Geom &g) { return tile_mcus(g) * g.nb * SLOT_WORDS_PE
 
 // srcs: host array of the nimg device pointers of a batch, or null for the single image `src`
 hipError_t launch_coded(const Geom &g, int algo, const uint8_t *src, const uint8_t *const *srcs, int nimg,
-                        const int16_t pred[3], const EntropyBufs &b, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+                        const int16_t pred[3], const EntropyBufs &b, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+                        int mcu_row0, int mcu_rows) {
+    if (mcu_rows < 0) mcu_rows = g.mcuy - mcu_row0;
     // rows are read as dwords (the caller checks the pointers of a batch)
     if (!srcs) nimg = 1;
     if ((g.stride & 3) || nimg < 1 || nimg > MAX_LAUNCH_IMAGES || !coded_supported(g)) return hipErrorInvalidValue;
     if (nimg != (b.nimg > 0 ? b.nimg : 1) || b.nchunks != coded_tiles(g)) return hipErrorInvalidValue;
-    CodedArgs a{{}, g, {pred[0], pred[1], pred[2]}, b.epoch, b.cstride, b.slot_words, b.clen, b.sparse, b.status};
+    CodedArgs a{{}, g, mcu_row0, {pred[0], pred[1], pred[2]}, b.epoch, b.cstride, b.slot_words, b.clen, b.sparse, b.status};
     for (int i = 0; i < nimg; i++) {
         a.src[i] = srcs ? srcs[i] : src;
         if (!a.src[i] || (reinterpret_cast<uintptr_t>(a.src[i]) & 3)) return hipErrorInvalidValue;   // rows are read as dwords
     }
-    if (g.h == 2 && g.v == 2) return launch_coded_hv<2, 2>(a, algo, nimg, s, e0, e1);
-    if (g.h == 2 && g.v == 1) return launch_coded_hv<2, 1>(a, algo, nimg, s, e0, e1);
-    if (g.h == 1 && g.v == 1) return launch_coded_hv<1, 1>(a, algo, nimg, s, e0, e1);
+    if (g.h == 2 && g.v == 2) return launch_coded_hv<2, 2>(a, algo, nimg, mcu_rows, s, e0, e1);
+    if (g.h == 2 && g.v == 1) return launch_coded_hv<2, 1>(a, algo, nimg, mcu_rows, s, e0, e1);
+    if (g.h == 1 && g.v == 1) return launch_coded_hv<1, 1>(a, algo, nimg, mcu_rows, s, e0, e1);
     return hipErrorInvalidValue;
 }
 

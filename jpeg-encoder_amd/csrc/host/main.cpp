@@ -5,6 +5,10 @@
 // reference): --device N, --fused, --stripes N with --devices a,b,.. (one image cut
 // into MCU-row stripes coded on several GPUs), and --image given more than once (a batch).
 #include <cstdint>
+#include <fcntl.h>
+#include <sys/uio.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -287,8 +291,15 @@ void encode_one(const Args &args, const std::string &image, const std::string &o
     uint8_t *scan = nullptr;
     size_t scan_len = 0;
     std::vector<uint8_t> staged_scan;
+    uint8_t header[1024];
+    size_t header_len = 0;
     if (args.fused) {
-        st = jpg_encode_scan(ctx, bmp.pixels, bmp.width, bmp.height, bmp.row_stride, 1, &scan, &scan_len);
+        // The encode is queued (rows copied and coded band by band) and the file's header is put together while
+        // the device works; header, scan and end marker then leave in one write.
+        st = jpg_encode_scan_begin(ctx, bmp.pixels, bmp.width, bmp.height, bmp.row_stride, 1);
+        if (st != JPG_OK) fail(ctx, st);
+        header_len = jph_jfif_header(header, sizeof header, bmp.width, bmp.height, h, v);
+        st = jpg_encode_scan_end(ctx, &scan, &scan_len);
         if (st != JPG_OK) fail(ctx, st);
         std::printf("Loaded!\nChrominance downsampling...\nDone!\n");
         std::printf("Performing Discrete Cosine Transform + Quantization...\nDone!\nEntropy encoding...\nDone!\n");
@@ -314,8 +325,29 @@ void encode_one(const Args &args, const std::string &image, const std::string &o
         staged_scan.resize(scan_len ? scan_len : 1);
         if ((st = jpg_get_scan(ctx, staged_scan.data(), staged_scan.size())) != JPG_OK) fail(ctx, st);
     }
-    const uint8_t *bytes = args.fused ? scan : staged_scan.data();
-    const int we = jph_jpeg_write(output.c_str(), bmp.width, bmp.height, h, v, bytes, scan_len);
+    int we = JPH_OK;
+    if (args.fused) {
+        static const uint8_t eoi[2] = {0xFF, 0xD9};   // src/jpeg/file.rs:134
+        const int fd = ::open(output.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0 || header_len == 0) {
+            we = JPH_ERR_IO;
+        } else {
+            iovec part[3] = {{header, header_len}, {scan, scan_len}, {const_cast<uint8_t *>(eoi), sizeof eoi}};
+            size_t left = header_len + scan_len + sizeof eoi;
+            int k = 0;
+            while (left && we == JPH_OK) {             // (a write may stop short of the whole)
+                const ssize_t n = ::writev(fd, part + k, 3 - k);
+                if (n <= 0) { we = JPH_ERR_IO; break; }
+                left -= (size_t)n;
+                size_t done = (size_t)n;
+                while (k < 3 && done >= part[k].iov_len) done -= part[k++].iov_len;
+                if (k < 3) { part[k].iov_base = static_cast<uint8_t *>(part[k].iov_base) + done; part[k].iov_len -= done; }
+            }
+        }
+        if (fd >= 0 && ::close(fd) != 0) we = JPH_ERR_IO;
+    } else {
+        we = jph_jpeg_write(output.c_str(), bmp.width, bmp.height, h, v, staged_scan.data(), scan_len);
+    }
     if (scan) jpg_free(scan);
     jpg_destroy(ctx);
     jpg_free(bmp.pixels);

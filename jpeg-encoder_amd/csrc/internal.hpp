@@ -104,9 +104,11 @@ hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred
 bool coded_supported(const Geom &g);
 long long coded_tiles(const Geom &g);
 int coded_slot_words(const Geom &g);
+// mcu_row0 / mcu_rows: the band of MCU rows this launch codes (default: all); the bands of an image are
+// launched in order on one stream, each reading the pixel rows of its own MCU rows and of the one above.
 hipError_t launch_coded(const Geom &g, int algo, const uint8_t *src, const uint8_t *const *srcs, int nimg,
                         const int16_t pred[3], const EntropyBufs &b, hipStream_t s, hipEvent_t e0 = nullptr,
-                        hipEvent_t e1 = nullptr);
+                        hipEvent_t e1 = nullptr, int mcu_row0 = 0, int mcu_rows = -1);
 // the DC coefficients of the last Y, Cb, Cr blocks of the image, computed from its pixels
 hipError_t launch_last_dc_pixels(const Geom &g, int algo, const uint8_t *src, int16_t *dc3, hipStream_t s);
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s);

@@ -432,3 +432,48 @@ def test_batches_match_single_images(J, oracle, ratio, algo, w, h, n):
     np.testing.assert_array_equal(enc.encode_scan(imgs[0], w, h), refs[0].stuffed_scan())
     with pytest.raises(J.JpgError):
         enc.encode_batch_device_async(ptrs * 80, w, h, imgs[0].shape[1], True)  # more than jpg_max_batch
+
+
+@pytest.mark.parametrize("ratio,algo,w,h", [
+    ((4, 2, 0), "bin-dct", 1024, 1600),          # 100 MCU rows: four bands
+    ((4, 2, 0), "real-dct-strict", 1000, 777),   # ragged height and width, two bands
+    ((4, 4, 4), "bin-dct", 600, 1000),           # 125 MCU rows of 8
+    ((4, 2, 2), "bin-dct", 1100, 300),
+])
+def test_host_rows_coded_band_by_band(J, oracle, monkeypatch, ratio, algo, w, h):
+    """jpg_encode_scan of rows in host memory copies and codes the image in bands of MCU rows; begin/end leave
+    room for the caller's own work in between.  Pageable and page-locked rows, bottom-up and top-down, a pitch
+    that is no multiple of four: all the oracle's bytes."""
+    import ctypes as C
+    L = J._native.lib()
+    a = oracle.BIN if algo == "bin-dct" else oracle.REAL
+    rows = J.host.synth_bgr(w, h, seed=61, noise_only=True)
+    stride = rows.shape[1]
+    want = oracle.RefImage.from_bgr(rows, w, h, stride, ratio, a).encode().stuffed_scan()
+    enc = J.Encoder(ratio, algo)
+    for rep in range(3):                                      # (later calls reuse the context's buffers)
+        if rep == 2:
+            monkeypatch.setenv("JPG_BANDS", "5")              # pageable rows are one band unless told otherwise
+        np.testing.assert_array_equal(enc.encode_scan(rows, w, h), want)
+    monkeypatch.delenv("JPG_BANDS")
+    # page-locked rows, in two steps
+    ptr = L.jpg_host_alloc(rows.nbytes)
+    C.memmove(ptr, rows.ctypes.data, rows.nbytes)
+    enc._ck(L.jpg_encode_scan_begin(enc._ctx, ptr, w, h, stride, 1))
+    header = J.host.jfif_header(w, h, enc.h, enc.v)           # (the host's own work meanwhile)
+    p, n = C.c_void_p(), C.c_size_t()
+    enc._ck(L.jpg_encode_scan_end(enc._ctx, C.byref(p), C.byref(n)))
+    got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,)).copy()
+    L.jpg_free(p)
+    L.jpg_free(ptr)
+    np.testing.assert_array_equal(got, want)
+    assert len(header) == 623
+    assert L.jpg_encode_scan_end(enc._ctx, C.byref(p), C.byref(n)) < 0      # nothing begun
+    for c in range(3):                                        # coefficients on request still work afterwards
+        np.testing.assert_array_equal(enc.coeffs(c), oracle.RefImage.from_bgr(rows, w, h, stride, ratio, a).encode().coeffs(c))
+    # top-down rows with a pitch of 3*w + 1
+    odd = 3 * w + 1
+    td = np.zeros((h, odd), np.uint8)
+    td[:, :3 * w] = rows[::-1, :3 * w]
+    np.testing.assert_array_equal(enc.encode_scan(td, w, h, odd, bottom_up=False), want)
+    enc.close()
