@@ -37,13 +37,17 @@ def content(w, h, kind, stride):
 
 
 t0 = time.time()
-done = fused = 0
+done = fused = static = 0
+import ctypes as C  # noqa: E402
+L = J._native.lib()
 for it in range(cases):
     ratio = RATIOS[int(rng.integers(3))]
     algo, ref_algo = ALGOS[int(rng.integers(2))]
     wide = rng.random() < 0.6
     w = int(rng.integers(512, 2600)) if wide else int(rng.integers(1, 512))
     h = int(rng.integers(1, 120 if wide else 400))
+    if wide and rng.random() < 0.1:
+        h = int(rng.integers(1024, 1500))                       # tall enough for several bands of MCU rows
     hs, vs = J.get_downsampling_factor(ratio)
     if (hs == 2 and w % 16 == 1) or (vs == 2 and h % 16 == 1):
         w += 1 if hs == 2 and w % 16 == 1 else 0
@@ -54,7 +58,7 @@ for it in range(cases):
     rows = content(w, h, kind, stride)
     want = refcpu.RefImage.from_bgr(rows, w, h, stride, ratio, ref_algo, bottom_up=bottom_up).encode().stuffed_scan()
     enc = encs.setdefault((ratio, algo), J.Encoder(ratio, algo))
-    mode = int(rng.integers(4))
+    mode = int(rng.integers(5))
     if mode == 3:
         # MCU-row stripes on separate contexts, stitched
         n = int(rng.integers(2, 6))
@@ -64,8 +68,27 @@ for it in range(cases):
         got = np.concatenate([j.place(codes) for j in jobs])
         for j in jobs:
             j.backend.close()
-    elif mode == 0 or stride % 4:
+    elif mode == 4 and stride % 4 == 0 and L.jpg_static_scan_capacity(w, h, *ratio) and w * h < 3000000:
+        # the encode that allocates nothing
+        cap = L.jpg_static_scan_capacity(w, h, *ratio)
+        t = torch.from_numpy(rows).cuda()
+        out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        res = torch.zeros(32, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        st = L.jpg_encode_device_static(0, J.jpeg_image.DCT_ALGORITHMS[algo], *ratio, t.data_ptr(), w, h, stride, int(bottom_up),
+                                        out.data_ptr(), cap, res.data_ptr(), None)
+        torch.cuda.synchronize()
+        r = J._native.StaticResult.from_buffer_copy(res.cpu().numpy().tobytes())
+        if st != 0 or L.jpg_static_status(C.byref(r)) != 0:
+            got = np.zeros(0, np.uint8) if st != -12 else want     # (too large for the working array: not a case)
+        else:
+            got = out[:r.scan_bytes].cpu().numpy()
+            static += 1
+    elif mode == 0 or mode == 4 or stride % 4:
+        if rng.random() < 0.3:
+            os.environ["JPG_BANDS"] = str(int(rng.integers(1, 7)))
         got = enc.encode_scan(rows, w, h, stride, bottom_up)
+        os.environ.pop("JPG_BANDS", None)
     elif mode == 1:
         t = torch.from_numpy(rows).cuda()
         torch.cuda.synchronize()
@@ -90,4 +113,4 @@ for it in range(cases):
     fused += int(enc.fused_coding())
     if it % 25 == 24:
         print("%d cases ok (%d through the fused coding kernel), %.0f s" % (done, fused, time.time() - t0), flush=True)
-print("fuzz ok: %d cases, %d through the fused coding kernel" % (done, fused))
+print("fuzz ok: %d cases, %d through the fused coding kernel, %d through the entry point that allocates nothing" % (done, fused, static))
