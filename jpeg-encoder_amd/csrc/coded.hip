@@ -48,7 +48,7 @@ struct CodedArgs {
 };
 
 template <int HS, int VS, int ALGO>
-__global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
+__device__ __forceinline__ void coded_tile(const CodedArgs &a) {
     using C = TileCfg<HS, VS>;
     constexpr int HV = HS * VS;
     static_assert(C::BLOCKS % 64 == 0 && C::BLOCKS <= THREADS, "one thread per block");
@@ -185,6 +185,20 @@ __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
     }
 }
 
+template <int HS, int VS, int ALGO>
+__global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
+    coded_tile<HS, VS, ALGO>(a);
+}
+
+// The same kernel held to the 128 registers that let a fourth wave share a SIMD.  The integer transform
+// wants a few more (134); with the cap a handful of values go to scratch memory and the kernel is a tenth faster
+// (3840x2160 4:4:4: 0.83 ms instead of 0.91 ms per 32 images).  Only where LDS leaves room for a fourth
+// workgroup per CU, which the tiles of 1024 pixels (4:2:2) do not.
+template <int HS, int VS, int ALGO>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_coded_4waves(CodedArgs a) {
+    coded_tile<HS, VS, ALGO>(a);
+}
+
 // The DC coefficients of the last Y, Cb, Cr blocks of MCU (mx, my), straight from the pixels: what a
 // following stripe starts its predictors from (src/jpeg/entropy_coding.rs:149-150).  One wave.
 template <int HS, int VS, int ALGO>
@@ -236,7 +250,10 @@ static hipError_t launch_coded_hv(const CodedArgs &a, int algo, int nimg, int mc
     const dim3 grid((unsigned)tiles_x, (unsigned)mcu_rows, (unsigned)nimg), block(THREADS);
     switch (algo) {
         case ALGO_REAL: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, a); break;
-        case ALGO_BIN: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, a); break;
+        case ALGO_BIN:
+            if constexpr (TileCfg<HS, VS>::TW == 512) hipExtLaunchKernelGGL((k_coded_4waves<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, a);
+            else hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, a);
+            break;
         case ALGO_REAL_STRICT: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_REAL_STRICT>), grid, block, 0, s, e0, e1, 0, a); break;
         default: return hipErrorInvalidValue;
     }

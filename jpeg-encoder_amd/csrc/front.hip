@@ -19,8 +19,8 @@ namespace jpg {
 // A batch of equally sized images is one launch: srcs[i] (when given) is the pixel array of image
 // i, whose tiles follow those of image i-1 in the grid and whose blocks follow in `coef`.
 template <int HS, int VS, int ALGO>
-__global__ __launch_bounds__(THREADS) void k_front(const uint8_t *__restrict__ src, const uint8_t *const *__restrict__ srcs,
-                                                   Geom g, int16_t *__restrict__ coef) {
+__device__ __forceinline__ void front_tile(const uint8_t *__restrict__ src, const uint8_t *const *__restrict__ srcs,
+                                           const Geom &g, int16_t *__restrict__ coef) {
     using C = TileCfg<HS, VS>;
     // Y plane, then Cb, Cr planes of the tile; phase B reuses the space for the finished blocks
     __shared__ __attribute__((aligned(16))) uint8_t lds[C::LDS_BYTES];
@@ -53,6 +53,19 @@ __global__ __launch_bounds__(THREADS) void k_front(const uint8_t *__restrict__ s
         dst[u] = *reinterpret_cast<const uint4 *>(&lds[(u >> 3) * OUT_STRIDE + (u & 7) * 16]);
 }
 
+template <int HS, int VS, int ALGO>
+__global__ __launch_bounds__(THREADS) void k_front(const uint8_t *__restrict__ src, const uint8_t *const *__restrict__ srcs,
+                                                   Geom g, int16_t *__restrict__ coef) {
+    front_tile<HS, VS, ALGO>(src, srcs, g, coef);
+}
+
+// The same kernel held to 128 registers (a fourth wave per SIMD) for the integer transform, which wants 130.
+template <int HS, int VS, int ALGO>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_front_4waves(
+    const uint8_t *__restrict__ src, const uint8_t *const *__restrict__ srcs, Geom g, int16_t *__restrict__ coef) {
+    front_tile<HS, VS, ALGO>(src, srcs, g, coef);
+}
+
 // e0/e1 (both or neither): events that receive the kernel's own start and end time stamps
 template <int HS, int VS>
 static hipError_t launch_front_hv(const Geom &g, int algo, const uint8_t *src, const uint8_t *const *srcs, int nimg,
@@ -64,7 +77,7 @@ static hipError_t launch_front_hv(const Geom &g, int algo, const uint8_t *src, c
     const dim3 grid((unsigned)tiles_x, (unsigned)g.mcuy, (unsigned)nimg), block(THREADS);
     switch (algo) {
         case ALGO_REAL: hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, src, srcs, g, coef); break;
-        case ALGO_BIN: hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, src, srcs, g, coef); break;
+        case ALGO_BIN: hipExtLaunchKernelGGL((k_front_4waves<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, src, srcs, g, coef); break;
         case ALGO_REAL_STRICT:
             hipExtLaunchKernelGGL((k_front<HS, VS, ALGO_REAL_STRICT>), grid, block, 0, s, e0, e1, 0, src, srcs, g, coef);
             break;
