@@ -28,7 +28,10 @@ namespace jpg {
 
 // LDS words a tile's bits are assembled in per pass.  (512 words would allow a fifth workgroup per CU:
 // 2 % faster on photo-like content, 23 % slower on noise, whose tiles then take 8 passes instead of 2.)
-constexpr int WIN_WORDS = 2048;
+// At tiles of 1024 pixels (4:2:2, 256 blocks of 144 bytes in LDS) only a window of 256 words leaves room for a
+// fourth workgroup per CU; their tiles hold about 4000 bits on photo-like content, one pass as a rule.
+template <int HS, int VS>
+constexpr int win_words() { return TileCfg<HS, VS>::TW == 1024 ? 256 : 2048; }
 
 constexpr int MAX_LAUNCH_IMAGES = 64;   // images of one launch: their pixel pointers travel in the argument block
 
@@ -57,6 +60,7 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
     __shared__ __attribute__((aligned(16))) uint8_t sHalo[C::HALO_BYTES];   // planes of the MCU before the tile
     __shared__ int16_t sHaloDc[4];                                          // its last Y, Cb, Cr DC coefficients
     __shared__ uint32_t sLut[LUT_WORDS];
+    constexpr int WIN_WORDS = win_words<HS, VS>();
     __shared__ uint32_t sWin[WIN_WORDS + 2];
     __shared__ uint32_t sTot[THREADS / 64], sPass[THREADS / 64];
     uint8_t *sY = lds;
@@ -249,10 +253,12 @@ static hipError_t launch_coded_hv(const CodedArgs &a, int algo, int nimg, int mc
     if (mcu_rows < 1 || a.mcu_row0 < 0 || a.mcu_row0 + mcu_rows > a.g.mcuy) return hipErrorInvalidValue;
     const dim3 grid((unsigned)tiles_x, (unsigned)mcu_rows, (unsigned)nimg), block(THREADS);
     switch (algo) {
-        case ALGO_REAL: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, a); break;
+        case ALGO_REAL:
+            if constexpr (TileCfg<HS, VS>::TW == 1024) hipExtLaunchKernelGGL((k_coded_4waves<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, a);
+            else hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, a);
+            break;
         case ALGO_BIN:
-            if constexpr (TileCfg<HS, VS>::TW == 512) hipExtLaunchKernelGGL((k_coded_4waves<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, a);
-            else hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, a);
+            hipExtLaunchKernelGGL((k_coded_4waves<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, a);
             break;
         case ALGO_REAL_STRICT: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_REAL_STRICT>), grid, block, 0, s, e0, e1, 0, a); break;
         default: return hipErrorInvalidValue;
