@@ -48,7 +48,20 @@ struct CodedArgs {
     uint32_t *clen;               // [nimg][cstride] out: bits of each tile
     uint32_t *sparse;             // [nimg][cstride][slot_words] out: the tile's bits, MSB first in each word
     DevStatus *status;            // [nimg]
+#ifdef JPG_PHASE_STAMPS
+    unsigned long long *stamps;   // [nimg][cstride][4 waves][STAMP_WORDS] out: clock readings of the instrumented build
+#endif
 };
+
+#ifdef JPG_PHASE_STAMPS
+// Instrumented build (tools/phase_stamps.py): every wave reads the shader clock at the phase boundaries and leaves
+// the readings, with the id of the SIMD it ran on, in the buffer given to jpg_debug_phase_stamps.
+constexpr int STAMP_WORDS = 10;
+static unsigned long long *g_stamps = nullptr;
+#define STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i]) : : "memory")
+#else
+#define STAMP(i)
+#endif
 
 template <int HS, int VS, int ALGO>
 __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
@@ -67,6 +80,10 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
     uint8_t *sCb = lds + C::TILE_H * C::TW;
     uint8_t *sCr = sCb + 8 * C::CW;
     const Geom &g = a.g;
+#ifdef JPG_PHASE_STAMPS
+    unsigned long long stamp[8];
+    STAMP(0);
+#endif
 
     // grid: x = tile column, y = MCU row (counted from the first row of the launch: a launch may cover a band of
     // rows, the rows above it being coded by earlier launches), z = image of a batch; no divisions to find the tile
@@ -89,12 +106,25 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
 #pragma unroll
     for (int k = 0; k < LUT_ROUNDS; k++) lut_words[k] = (&HUFF_DEV.e[0][0])[min(tid + k * THREADS, LUT_WORDS - 1)];
 
+#ifdef JPG_PHASE_STAMPS
+    stamp[1] = stamp[0];
+    // (JPG_STAMP_LAST: the reading is taken when the last pixels have arrived instead of the first)
+    tile_convert<HS, VS>(src, g, x0, y0, mcus, sY, sCb, sCr, tid, [&](uint32_t first, uint32_t last) {
+#ifdef JPG_STAMP_LAST
+        first = last;
+#endif
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[1]) : "v"(first) : "memory");
+    });
+    STAMP(2);
+#else
     tile_convert<HS, VS>(src, g, x0, y0, mcus, sY, sCb, sCr, tid);
+#endif
 #pragma unroll
     for (int k = 0; k < LUT_ROUNDS; k++)
         if (tid + k * THREADS < LUT_WORDS) sLut[tid + k * THREADS] = lut_words[k];
     for (int i = tid; i < WIN_WORDS + 2; i += THREADS) sWin[i] = 0;   // (after the loads, like the table)
     __syncthreads();
+    STAMP(3);
     tile_transform<HS, VS, ALGO>(lds, mcus, tid, [&] {
         if (!has_halo) return;
         HaloRegs<VS> halo;
@@ -103,7 +133,9 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
         __builtin_amdgcn_wave_barrier();   // (the LDS accesses of one wave execute in order)
         halo_dc<HS, VS, ALGO>(sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, sHaloDc);
     });
+    STAMP(4);
     __syncthreads();
+    STAMP(5);
 
     // ---------------- coding: thread `tid` codes block `tid` of the tile ----------------
     const int nblk = mcus * C::NBLK;
@@ -132,6 +164,7 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
         lut = sLut + (comp ? jpgtab::HUFF_LUT_STRIDE : 0);
         len = code_block(slot, mlo, mhi, dc_diff, lut, status, a.epoch, acc);
     }
+    STAMP(6);
     const uint32_t sc = wave_incl_scan(len);
     if (lane == 63) sTot[wave] = sc;
     __syncthreads();
@@ -187,7 +220,24 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
         for (uint32_t i = tid; i < nwords + 1; i += THREADS) sWin[i] = i ? 0u : carry;
         __syncthreads();
     }
+#ifdef JPG_PHASE_STAMPS
+    STAMP(7);
+    if (a.stamps && lane == 0) {
+        unsigned long long *o = a.stamps + (slot_index * (THREADS / 64) + wave) * STAMP_WORDS;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] = stamp[i];
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[8] = hw;
+        o[9] = xcc;
+    }
+#endif
 }
+
+#ifdef JPG_PHASE_STAMPS
+extern "C" void jpg_debug_phase_stamps(void *dev_buffer) { g_stamps = static_cast<unsigned long long *>(dev_buffer); }
+#endif
 
 template <int HS, int VS, int ALGO>
 __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
@@ -288,6 +338,9 @@ hipError_t launch_coded(const Geom &g, int algo, const uint8_t *src, const uint8
     if ((g.stride & 3) || nimg < 1 || nimg > MAX_LAUNCH_IMAGES || !coded_supported(g)) return hipErrorInvalidValue;
     if (nimg != (b.nimg > 0 ? b.nimg : 1) || b.nchunks != coded_tiles(g)) return hipErrorInvalidValue;
     CodedArgs a{{}, g, mcu_row0, {pred[0], pred[1], pred[2]}, b.epoch, b.cstride, b.slot_words, b.clen, b.sparse, b.status};
+#ifdef JPG_PHASE_STAMPS
+    a.stamps = g_stamps;
+#endif
     for (int i = 0; i < nimg; i++) {
         a.src[i] = srcs ? srcs[i] : src;
         if (!a.src[i] || (reinterpret_cast<uintptr_t>(a.src[i]) & 3)) return hipErrorInvalidValue;   // rows are read as dwords

@@ -365,24 +365,25 @@ __device__ __forceinline__ void lds_barrier() {
 #define JPG_STAMP(K) do { } while (0)
 #endif
 
-#ifndef JPG_ST_THREADS
-#define JPG_ST_THREADS 512
-#endif
-constexpr int ST_THREADS = JPG_ST_THREADS;    // threads per segment
-constexpr int ST_WAVES = ST_THREADS / 64;
-constexpr int WPT = SEG_WORDS / ST_THREADS;   // 32-bit words of the segment per thread
-constexpr int DIRECT_ITEMS = ST_THREADS;      // segments whose predecessors' counts are read directly, one per thread
-constexpr int GATHER_ROUNDS = (DENSE_WORDS + 2 * 132 + ST_THREADS - 1) / ST_THREADS;
-static_assert(SEG_WORDS == WPT * ST_THREADS && ST_THREADS >= TABLE, "whole words per thread");
+// Threads per segment: 512 for a single image, whose stuffing nothing else hides (the kernel is a chain of short
+// dependent steps, and more waves keep the per-thread instruction count of every step small); 256 for a batch,
+// which is stuffed beside the coding kernel of the next batch: one wave per SIMD, 64 registers and under 8 KiB of
+// LDS fit into what four workgroups of the coding kernel leave free on a CU.
+constexpr int ST_THREADS_SINGLE = 512, ST_THREADS_BATCH = 256;
 
 // STUFF: byte stuffing of the (shifted) stream into a.out, a workgroup per segment of
 // STUFF_SEG stream bytes (blockIdx.x, + gridDim.x, ...).  !STUFF: the stream itself, dense.
 // Dynamic LDS: (ngroups + 1) 64-bit prefix sums of the chunk lengths per group.
-// The kernel is a chain of short dependent steps; 16 waves per workgroup keep the per-thread
-// instruction count of every step small (a lone wave issues an instruction only every ~5 ns).
-template <bool STUFF>
-// (8 waves per SIMD = 4 workgroups per CU: the more segments are in flight, the shorter the chain per workgroup)
+// The kernel is a chain of short dependent steps.  Four waves per workgroup: one per SIMD, which is what fits
+// beside the workgroups of the coding kernel of the next batch (see launch_stream).
+template <bool STUFF, int ST_THREADS>
+// (at most 64 registers: eight waves per SIMD when it has the device to itself)
 __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_stream(StreamArgs a) {
+    constexpr int ST_WAVES = ST_THREADS / 64;
+    constexpr int WPT = SEG_WORDS / ST_THREADS;   // 32-bit words of the segment per thread
+    constexpr int DIRECT_ITEMS = ST_THREADS;      // segments whose predecessors' counts are read directly, one per thread
+    constexpr int GATHER_ROUNDS = (DENSE_WORDS + 2 * 132 + ST_THREADS - 1) / ST_THREADS;
+    static_assert(SEG_WORDS == WPT * ST_THREADS && ST_THREADS >= TABLE, "whole words per thread");
     {   // this workgroup's image: from here on `a` describes that image alone
         const int img = blockIdx.x / a.wpi;
         a.sparse += (size_t)img * a.cstride * a.slot_words;
@@ -743,9 +744,9 @@ hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred
     return hipGetLastError();
 }
 
-template <bool STUFF>
-static hipError_t launch_stream(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, uint8_t *out,
-                                size_t out_stride, hipStream_t s) {
+template <bool STUFF, int ST_THREADS>
+static hipError_t launch_stream_threads(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last,
+                                        uint8_t *out, size_t out_stride, hipStream_t s) {
     const int nimg = b.nimg > 0 ? b.nimg : 1;
     const int ngroups = (int)((b.nchunks + 63) / 64);
     if (ngroups > MAX_GROUPS || !out || b.slot_words <= 0 || (STUFF && !b.sticket)) return hipErrorInvalidValue;
@@ -756,22 +757,27 @@ static hipError_t launch_stream(const EntropyBufs &b, uint64_t bit_offset, uint8
     // rounded up to 4 KiB).
     constexpr size_t LDS_CLASS = 4096;
     constexpr int NCLASS = (int)(((MAX_GROUPS + 1) * sizeof(uint64_t) + LDS_CLASS - 1) / LDS_CLASS) + 1;
-    static std::atomic<long long> resident_cache[2][64][NCLASS] = {};   // device properties, not state
+    static std::atomic<long long> resident_cache[64][NCLASS] = {};   // device properties, not state
     const int cls = (int)((lds + LDS_CLASS - 1) / LDS_CLASS);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    long long resident = dev >= 0 && dev < 64 ? resident_cache[STUFF][dev][cls].load(std::memory_order_relaxed) : 0;
+    long long resident = dev >= 0 && dev < 64 ? resident_cache[dev][cls].load(std::memory_order_relaxed) : 0;
     if (resident == 0) {
         int cus = 0, per_cu = 0;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<STUFF>, ST_THREADS, (size_t)cls * LDS_CLASS);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<STUFF, ST_THREADS>, ST_THREADS,
+                                                             (size_t)cls * LDS_CLASS);
         if (e != hipSuccess) return e;
         resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
-        if (dev >= 0 && dev < 64) resident_cache[STUFF][dev][cls].store(resident, std::memory_order_relaxed);
+        if (dev >= 0 && dev < 64) resident_cache[dev][cls].store(resident, std::memory_order_relaxed);
     }
     size_t cap = (size_t)resident;
+    // A batch is stuffed while the coding kernel of the next batch runs: two workgroups per CU take nothing from
+    // it; with more, the two kernels compete for the slots (7680x4320 batches: 865 K MP/s with two per CU, 828 K
+    // with eight, 856 K with one for every second CU).
+    if (ST_THREADS == ST_THREADS_BATCH && cap > (size_t)resident / 4) cap = (size_t)resident / 4;
     if (b.stuff_grid && b.stuff_grid < cap) cap = b.stuff_grid;
     if ((size_t)nimg > cap) return hipErrorInvalidValue;       // the caller splits larger batches
     size_t wpi = cap / nimg;                                     // workgroups per image
@@ -779,8 +785,15 @@ static hipError_t launch_stream(const EntropyBufs &b, uint64_t bit_offset, uint8
     StreamArgs a{b.sparse, b.clen, b.nchunks, ngroups, (int)wpi, b.cstride, (size_t)b.slot_words, out_stride, b.nseg_cap, b.nseg_cap / 64 + 1,
                  b.nseg_cap / 4096 + 1, b.status, (uint32_t)(bit_offset & 7), head_bits, is_last, b.sagg, b.sgrp, b.shyp,
                  b.sticket, b.stuff_epoch, b.epoch, out, b.host_status, b.trace};
-    hipLaunchKernelGGL(k_stream<STUFF>, dim3((unsigned)(wpi * nimg)), dim3(ST_THREADS), lds, s, a);
+    hipLaunchKernelGGL((k_stream<STUFF, ST_THREADS>), dim3((unsigned)(wpi * nimg)), dim3(ST_THREADS), lds, s, a);
     return hipGetLastError();
+}
+
+template <bool STUFF>
+static hipError_t launch_stream(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, uint8_t *out,
+                                size_t out_stride, hipStream_t s) {
+    if (b.nimg > 1) return launch_stream_threads<STUFF, ST_THREADS_BATCH>(b, bit_offset, head_bits, is_last, out, out_stride, s);
+    return launch_stream_threads<STUFF, ST_THREADS_SINGLE>(b, bit_offset, head_bits, is_last, out, out_stride, s);
 }
 
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s) {

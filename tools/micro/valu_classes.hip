@@ -90,7 +90,14 @@
     X(v_fmaak_f32, "v_fmaak_f32 %0, %0, %2, 0x3e991687") \
     X(v_mad_i64_i32, "v_mad_i64_i32 %1, s[20:21], %0, %2, %1") \
     X(v_lshlrev_b64, "v_lshlrev_b64 %1, 3, %1") \
-    X(v_mad_u64_u32, "v_mad_u64_u32 %1, vcc, %0, %2, %1")
+    X(v_mad_u64_u32, "v_mad_u64_u32 %1, vcc, %0, %2, %1") \
+    X(v_pk_mul_f32_half_count, "v_pk_mul_f32 %1, %1, %5") \
+    X(v_pk_add_f32_half_count, "v_pk_add_f32 %1, %1, %5") \
+    X(v_pk_mul_f32_sgpr_low_for_both, "v_pk_mul_f32 %1, %1, s[20:21] op_sel_hi:[1,0]") \
+    X(s_mov_then_v_mul_f32, "s_mov_b32 s20, 0x3e991687\n\tv_mul_f32 %0, s20, %0") \
+    X(two_s_mov_then_v_pk_mul_f32, "s_mov_b32 s20, 0x3e991687\n\ts_mov_b32 s21, 0x3e991688\n\tv_pk_mul_f32 %1, %1, s[20:21]") \
+    X(s_nop_then_v_mul_f32, "s_nop 0\n\tv_mul_f32 %0, %0, %2") \
+    X(v_mul_f32_then_dependent_v_add_f32, "v_mul_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %3")
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
