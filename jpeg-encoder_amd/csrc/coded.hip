@@ -26,12 +26,15 @@
 
 namespace jpg {
 
-// LDS words a tile's bits are assembled in per pass.  (512 words would allow a fifth workgroup per CU:
-// 2 % faster on photo-like content, 23 % slower on noise, whose tiles then take 8 passes instead of 2.)
+// LDS words a tile's bits are assembled in per pass: 1536 (48 Kbit; tiles of photo-like content hold about 4 Kbit,
+// noise about 45 Kbit).  (512 words would allow a fifth workgroup per CU: 2 % faster on photo-like content, 23 %
+// slower on noise, whose tiles then take 8 passes; 2048 words is 0.5 % slower than 1536 on both kinds: four
+// workgroups then leave 10 KB of a CU's LDS free instead of 18, room for one instead of two workgroups of the
+// stuffing kernel that runs beside this one.)
 // At tiles of 1024 pixels (4:2:2, 256 blocks of 144 bytes in LDS) only a window of 256 words leaves room for a
 // fourth workgroup per CU; their tiles hold about 4000 bits on photo-like content, one pass as a rule.
 template <int HS, int VS>
-constexpr int win_words() { return TileCfg<HS, VS>::TW == 1024 ? 256 : 2048; }
+constexpr int win_words() { return TileCfg<HS, VS>::TW == 1024 ? 256 : 1536; }
 
 constexpr int MAX_LAUNCH_IMAGES = 64;   // images of one launch: their pixel pointers travel in the argument block
 

@@ -23,6 +23,7 @@ __host__ __device__ constexpr int tile_width(int hs, int vs) { return hs == 2 &&
 // array is "generic" to the compiler, which then emits flat loads that also count as LDS operations).
 typedef const __attribute__((address_space(1))) uint32_t *global_u32_ptr;
 typedef const __attribute__((address_space(1))) uint8_t *global_u8_ptr;
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 constexpr int OUT_STRIDE = 144; // bytes between parked blocks in LDS (128 + 16: conflict-free b128 access)
 constexpr int THREADS = 256;
 
@@ -237,22 +238,31 @@ __device__ __forceinline__ void tile_convert(const uint8_t *__restrict__ src, co
         uint32_t d[C::ROUNDS][VS][3];
         const int ix = tid % C::ROW_ITEMS;
         const bool present = ix < items_x;
-        // Addresses are a base that is the same for the whole workgroup (scalar registers) plus a 32-bit
-        // offset per lane: the item row of this thread within a round (the later row lies lower in a
-        // bottom-up file) and the 12 bytes per item.
+        // Buffer loads: the address is a descriptor with the tile's lowest row as its base (scalar registers, set up
+        // once), a scalar offset per row and a 32-bit offset per lane, so that no vector instruction and only two
+        // scalar ones per row go into addresses.  (Written with pointers the compiler forms a 64-bit address per row
+        // and lane: two 4-cycle vector and eight scalar instructions per row, a twentieth of the kernel.)
+        // A lane's offset: the 12 bytes per item and the item row of this thread within a round; in a bottom-up file
+        // the later row lies lower, so there the rows of a tile are counted from its last one.
         const int sub = tid / C::ROW_ITEMS;                     // 0 .. ROUND_ROWS-1
         const uint32_t lane_off = 12u * (uint32_t)ix +
                                   (uint32_t)(g.bottom_up ? C::ROUND_ROWS - 1 - sub : sub) * (uint32_t)VS * g.stride;
+        const size_t low_row = g.bottom_up ? (size_t)(g.H - y0 - C::TILE_H) : (size_t)y0;
+        const uint8_t *tile_base = src + low_row * g.stride + (size_t)3 * x0;
+        const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(tile_base), 0, 0x7fffffff, 0x00020000);
+        // row c of the tile (c = VS * ROUND_ROWS * k + r for the first item row of round k) lies c rows above the base
+        // in a top-down file and TILE_H - 1 - VS * (ROUND_ROWS - 1) - c rows in a bottom-up one
+        const uint32_t row_step = g.bottom_up ? 0u - g.stride : g.stride;
+        const uint32_t row_first = g.bottom_up ? (uint32_t)(C::TILE_H - 1 - VS * (C::ROUND_ROWS - 1)) * g.stride : 0u;
 #pragma unroll
         for (int k = 0; k < C::ROUNDS; k++) {
 #pragma unroll
             for (int r = 0; r < VS; r++) {
-                // row of sub-row 0 (top-down) or of the last sub-row (bottom-up): the lowest address of the round
-                const int y = y0 + C::ROUND_ROWS * k * VS + r;
-                const size_t row = g.bottom_up ? (size_t)(g.H - 1 - y - (C::ROUND_ROWS - 1) * VS) : (size_t)y;
-                const uint8_t *base = src + row * g.stride + (size_t)3 * x0;
-                const global_u32_ptr p = (global_u32_ptr)(base + lane_off);
-                if (present) { d[k][r][0] = p[0]; d[k][r][1] = p[1]; d[k][r][2] = p[2]; }
+                const uint32_t row_off = row_first + (uint32_t)(VS * C::ROUND_ROWS * k + r) * row_step;
+                if (present) {
+                    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rows, (int)lane_off, (int)row_off, 0);
+                    d[k][r][0] = v.x; d[k][r][1] = v.y; d[k][r][2] = v.z;
+                }
             }
         }
         loaded(d[0][0][0], d[C::ROUNDS - 1][VS - 1][2]);

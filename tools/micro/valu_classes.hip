@@ -97,7 +97,17 @@
     X(s_mov_then_v_mul_f32, "s_mov_b32 s20, 0x3e991687\n\tv_mul_f32 %0, s20, %0") \
     X(two_s_mov_then_v_pk_mul_f32, "s_mov_b32 s20, 0x3e991687\n\ts_mov_b32 s21, 0x3e991688\n\tv_pk_mul_f32 %1, %1, s[20:21]") \
     X(s_nop_then_v_mul_f32, "s_nop 0\n\tv_mul_f32 %0, %0, %2") \
-    X(v_mul_f32_then_dependent_v_add_f32, "v_mul_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %3")
+    X(v_mul_f32_then_dependent_v_add_f32, "v_mul_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %3") \
+    X(s_mov_b32_inline_then_v_mul_f32, "s_mov_b32 s20, 3\n\tv_mul_f32 %0, %0, %2") \
+    X(s_add_u32_then_v_mul_f32, "s_add_u32 s20, s20, 3\n\tv_mul_f32 %0, %0, %2") \
+    X(s_and_b64_then_v_mul_f32, "s_and_b64 s[20:21], s[20:21], exec\n\tv_mul_f32 %0, %0, %2") \
+    X(s_or_b64_exec_then_v_mul_f32, "s_or_b64 exec, exec, exec\n\tv_mul_f32 %0, %0, %2") \
+    X(s_cmp_cbranch_then_v_mul_f32, "s_cmp_eq_u32 s20, 77\n\ts_cbranch_scc1 1f\n1:\n\tv_mul_f32 %0, %0, %2") \
+    X(s_waitcnt_then_v_mul_f32, "s_waitcnt lgkmcnt(0)\n\tv_mul_f32 %0, %0, %2") \
+    X(s_mov_then_4_v_mul_f32, "s_mov_b32 s20, 0x3e991687\n\tv_mul_f32 %0, %0, %2\n\tv_mul_f32 %0, %0, %3\n\tv_mul_f32 %0, %0, %2\n\tv_mul_f32 %0, %0, %3") \
+    X(v_readfirstlane_then_v_mul_f32, "v_readfirstlane_b32 s20, %2\n\tv_mul_f32 %0, %0, %2") \
+    X(ds_read_b32_then_v_mul_f32, "ds_read_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)\n\tv_mul_f32 %0, %0, %2") \
+    X(s_mov_then_v_cvt, "s_mov_b32 s20, 3\n\tv_cvt_f32_ubyte0 %0, %0")
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, u
     case M_##name: {                                                                                            \
         _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                        \
             _Pragma("unroll") for (int i = 0; i < 16; i++)                                                      \
-                asm volatile(text : "+v"(a[i]), "+v"(p[i]) : "v"(c0), "v"(c1), "s"(sg), "v"(pc) : "s20", "s21");       \
+                asm volatile(text : "+v"(a[i]), "+v"(p[i]) : "v"(c0), "v"(c1), "s"(sg), "v"(pc) : "s20", "s21", "scc");       \
         }                                                                                                       \
     } break;
             MODES(X)
