@@ -82,6 +82,10 @@ def main():
     print("  CUs seen %d; workgroups resident per CU %.2f on average; a slot stands empty for %.0f ticks (median) between two workgroups"
           % (len(res), float(np.mean(res)), float(np.median(gaps))))
     print("  busy span of a CU %.0f ticks on average" % float(np.mean(spans)))
+    # which SIMD the waves of a workgroup run on (HW_ID bits 5:4)
+    simd = (hw >> 4) & 3
+    tab = [[int(((simd[:, :, w] == k).sum())) for k in range(4)] for w in range(4)]
+    print("  waves 0..3 of a workgroup on SIMD 0..3 (counts): %s" % tab)
     # which die a workgroup runs on, against its number in dispatch order (x fastest, then MCU row, then image)
     x = (xcc[:, :, 0] & 0xf).ravel()
     ident = np.arange(x.size)

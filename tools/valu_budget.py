@@ -132,6 +132,12 @@ def main():
     need = 2 * f32 + 4 * cvt + rest * (2 * (1 - share4) + 4 * share4)
     cycles = p["GRBM_GUI_ACTIVE"] / a.xcds                       # shader cycles the kernel ran (per XCD)
     have = a.simds * cycles
+    # Scalar instructions: next to 2-cycle vector instructions a scalar ALU instruction takes 4 cycles of the SIMD's
+    # issue time that no vector instruction of another wave fills (tools/micro/valu_classes.hip, the modes
+    # "s_..._then_v_mul_f32": 6 cycles per pair at four waves per SIMD, against 2 for the vector instruction alone;
+    # 3 for s_nop or s_waitcnt and a vector instruction); next to a 4-cycle vector instruction it takes 2.
+    salu = p.get("SQ_INSTS_SALU", 0.0)
+    need_with_salu = need + 3.0 * salu                          # between the 2 and the 4 cycles measured
     rec = {
         "workload": a.workload, "kernel": a.kernel, "images_per_launch_in_the_counter_run": n,
         "source": "tools/valu_budget.py over %s and %s" % (os.path.basename(a.classes), a.pmc),
@@ -145,6 +151,8 @@ def main():
         "valu_issue_cycles_per_launch": need / n,
         "simds": a.simds, "clock_ghz": 2.4,
         "frac_in_the_counter_run": round(need / have, 4),
+        "scalar_alu_instructions_per_launch": salu / n,
+        "frac_in_the_counter_run_with_scalar_instructions_at_3_cycles": round(need_with_salu / have, 4) if salu else None,
         "mean_issue_cycles_per_instruction": round(need / total, 3),
         "not_measured_one_by_one_priced_at_2_cycles": unknown,
         "waves_per_simd": round(p.get("SQ_WAVE_CYCLES", 0) * 4 / have, 3) if p.get("SQ_WAVE_CYCLES") else None,
@@ -158,6 +166,11 @@ def main():
                 % (f32, cvt, rest, 2 * (1 - share4) + 4 * share4, 100 * share4))
         f.write("  total             %12.0f  -> %.1f M issue cycles needed; %d SIMDs x %.0f cycles = %.1f M available: %.3f\n\n"
                 % (total, need / 1e6, a.simds, cycles, have / 1e6, need / have))
+        if salu:
+            f.write("scalar ALU instructions %12.0f per launch: next to vector instructions of another wave they take 4 cycles of the\n"
+                    "  SIMD's issue time beside a 2-cycle vector instruction and 2 beside a 4-cycle one (tools/micro/valu_classes.hip,\n"
+                    "  modes s_*_then_v_*); at 3 cycles each: %.1f M issue cycles needed in all: %.3f\n\n"
+                    % (salu, need_with_salu / 1e6, need_with_salu / have))
         f.write("ISA of the kernel (static counts, all paths), vector-ALU instructions by issue cost:\n")
         for cost in (2, 4, 8):
             items = sorted(((c, k) for k, (c, cc) in counts.items() if cc == cost), reverse=True)
