@@ -129,7 +129,11 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
     __syncthreads();
     STAMP(3);
     tile_transform<HS, VS, ALGO>(lds, mcus, tid, [&] {
-        if (!has_halo) return;
+        if (!has_halo) {
+            // first tile of the image: the caller's predictors, left where the coders look for the MCU before the tile
+            if (lane < 3) sHaloDc[lane] = lane == 0 ? a.pred[0] : (lane == 1 ? a.pred[1] : a.pred[2]);
+            return;
+        }
         HaloRegs<VS> halo;
         halo_load<HS, VS>(src, g, hmx * 8 * HS, hmy * 8 * VS, lane, halo);
         halo_convert<HS, VS>(src, g, hmx * 8 * HS, hmy * 8 * VS, sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, halo);
@@ -159,10 +163,9 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
         const int jb = tid % C::NBLK;
         const int comp = jb < HV ? 0 : jb - HV + 1;
         const int back = prev_distance(jb, C::NBLK, HV);
-        int pdc;
-        if (tid >= back) pdc = (int16_t) * reinterpret_cast<const uint16_t *>(&lds[(tid - back) * OUT_STRIDE]);
-        else if (has_halo) pdc = sHaloDc[comp];
-        else pdc = comp == 0 ? a.pred[0] : (comp == 1 ? a.pred[1] : a.pred[2]);
+        // (one LDS read at a selected address: the block before it in the tile, or the MCU before the tile)
+        const int16_t *prev = tid >= back ? reinterpret_cast<const int16_t *>(&lds[(tid - back) * OUT_STRIDE]) : &sHaloDc[comp];
+        const int pdc = *prev;
         dc_diff = (int16_t)((int)(int16_t)(q[0].x & 0xffff) - pdc);
         lut = sLut + (comp ? jpgtab::HUFF_LUT_STRIDE : 0);
         len = code_block(slot, mlo, mhi, dc_diff, lut, status, a.epoch, acc);
@@ -179,12 +182,12 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
         total += t;
     }
     const uint32_t end = before + sc;                         // bits of the tile up to and including this block
-    const size_t slot_index = (size_t)img * (size_t)a.cstride + (size_t)tile;
+    const uint32_t slot_index = (uint32_t)img * (uint32_t)a.cstride + (uint32_t)tile;   // (the launcher checks the range)
     if (tid == 0) a.clen[slot_index] = total;
 
     // A tile too long for the LDS window goes in several passes, each starting in the word the
     // previous one ended in (that word is carried over and stored again).
-    uint32_t *dst = a.sparse + slot_index * (size_t)a.slot_words;
+    uint32_t *dst = a.sparse + (uint64_t)slot_index * (uint32_t)a.slot_words;
     constexpr uint32_t WINDOW = WIN_WORDS * 32;               // bits per pass
     uint32_t done = 0;                                        // bits of the tile already stored
     for (;;) {
@@ -302,7 +305,7 @@ static hipError_t launch_coded_hv(const CodedArgs &a, int algo, int nimg, int mc
     const long long tiles = (long long)tiles_x * a.g.mcuy;
     if (tiles <= 0 || tiles * nimg > 0x7fffffffLL || tiles > a.cstride || a.slot_words != coded_slot_words(a.g))
         return hipErrorInvalidValue;
-    if (a.g.mcuy > 65535 || nimg > 65535) return hipErrorInvalidValue;
+    if (a.g.mcuy > 65535 || nimg > 65535 || a.cstride * nimg > 0xffffffffLL) return hipErrorInvalidValue;
     if (mcu_rows < 1 || a.mcu_row0 < 0 || a.mcu_row0 + mcu_rows > a.g.mcuy) return hipErrorInvalidValue;
     const dim3 grid((unsigned)tiles_x, (unsigned)mcu_rows, (unsigned)nimg), block(THREADS);
     switch (algo) {

@@ -160,19 +160,26 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x) {
     return x;
 }
 
+// acc = 2 * acc + x on both halves of a word at once (written out: the compiler has no pattern for it)
+__device__ __forceinline__ uint32_t halves_shift_in(uint32_t acc, uint32_t x) {
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(acc), "v"(x));   // (the low half of the constant for both)
+    return r;
+}
+
 // bit k set where the k-th int16 of the block (8 uint4) is non-zero: per 16 dwords the flags of
-// the low halves are collected in bits 0..15 and those of the high halves in bits 16..31, then the
-// two are interleaved
+// the low halves are collected in bits 0..15 and those of the high halves in bits 16..31 (one multiply-add per
+// dword, last dword first, shifts the flags in), then the two are interleaved
 __device__ __forceinline__ void nonzero_mask(const uint4 (&q)[8], uint32_t &mlo, uint32_t &mhi) {
     uint32_t m[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         uint32_t f = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 3; i >= 0; i--) {
             const uint32_t w[4] = {q[4 * h + i].x, q[4 * h + i].y, q[4 * h + i].z, q[4 * h + i].w};
 #pragma unroll
-            for (int j = 0; j < 4; j++) f |= halves_nonzero(w[j]) << (4 * i + j);
+            for (int j = 3; j >= 0; j--) f = (i == 3 && j == 3) ? halves_nonzero(w[j]) : halves_shift_in(f, halves_nonzero(w[j]));
         }
         m[h] = spread16(f & 0xffffu) | (spread16(f >> 16) << 1);
     }

@@ -382,35 +382,37 @@ __device__ __forceinline__ void tile_transform(uint8_t *lds, int mcus, int tid, 
     const uint8_t *sCb = lds + C::TILE_H * C::TW;
     const uint8_t *sCr = sCb + 8 * C::CW;
     const int wave = tid >> 6, lane = tid & 63;
+    // Every thread loads eight rows of samples, also the threads without a block (from a block that exists): with
+    // the loads under a condition the compiler fills the 16 registers with zeros on the other path, 32-48
+    // instructions per wave.
     uint32_t px[16];
     int bi = -1;                                               // block index inside the tile, scan order
     if (wave < C::YWAVES) {
         // luma: block row `brow`, block column `bcol` of the tile
         const int brow = wave / C::ROW_WAVES, bcol = (wave % C::ROW_WAVES) * 64 + lane;
         const int m = bcol / HS;                               // MCU inside the tile
-        if (m < mcus) {
+        const int col = m < mcus ? bcol : 0;
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(&sY[(brow * 8 + r) * C::TW + bcol * 8]);
-                px[2 * r] = v.x;
-                px[2 * r + 1] = v.y;
-            }
-            bi = m * C::NBLK + brow * HS + (bcol % HS);
+        for (int r = 0; r < 8; r++) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(&sY[(brow * 8 + r) * C::TW + col * 8]);
+            px[2 * r] = v.x;
+            px[2 * r + 1] = v.y;
         }
-    } else if (wave < C::YWAVES + C::CWAVES) {
-        const int ci = (wave - C::YWAVES) * 64 + lane;         // 0 .. 2*MCUS-1
+        if (m < mcus) bi = m * C::NBLK + brow * HS + (bcol % HS);
+    } else {
+        const int ci = (wave - C::YWAVES) * 64 + lane;         // 0 .. 2*MCUS-1; beyond that: the wave without blocks
         const int comp = ci / C::MCUS;                         // 0 Cb, 1 Cr
         const int m = ci % C::MCUS;
-        if (m < mcus) {
-            const uint8_t *pl = comp ? sCr : sCb;
+        const bool has = wave < C::YWAVES + C::CWAVES && m < mcus;
+        const uint8_t *pl = comp == 1 ? sCr : sCb;
+        const int col = has ? m : 0;
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(&pl[r * C::CW + m * 8]);
-                px[2 * r] = v.x;
-                px[2 * r + 1] = v.y;
-            }
-            bi = m * C::NBLK + HS * VS + comp;
+        for (int r = 0; r < 8; r++) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(&pl[r * C::CW + col * 8]);
+            px[2 * r] = v.x;
+            px[2 * r + 1] = v.y;
         }
+        if (has) bi = m * C::NBLK + HS * VS + comp;
     }
     __syncthreads();   // every sample is in registers: the planes' space becomes the output staging area
     if (bi >= 0) {
