@@ -128,6 +128,10 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
     for (int i = tid; i < WIN_WORDS + 2; i += THREADS) sWin[i] = 0;   // (after the loads, like the table)
     __syncthreads();
     STAMP(3);
+#if JPG_ABLATE >= 2   // (timing experiments: the kernel without its later phases; see tools/build_variant.py)
+    if (tid == 0) a.clen[(uint32_t)img * (uint32_t)a.cstride + (uint32_t)tile] = sY[5] & 1;
+    return;
+#endif
     tile_transform<HS, VS, ALGO>(lds, mcus, tid, [&] {
         if (!has_halo) {
             // first tile of the image: the caller's predictors, left where the coders look for the MCU before the tile
@@ -143,6 +147,10 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
     STAMP(4);
     __syncthreads();
     STAMP(5);
+#if JPG_ABLATE == 1
+    if (tid == 0) a.clen[(uint32_t)img * (uint32_t)a.cstride + (uint32_t)tile] = lds[5] & 1;
+    return;
+#endif
 
     // ---------------- coding: thread `tid` codes block `tid` of the tile ----------------
     const int nblk = mcus * C::NBLK;

@@ -270,6 +270,10 @@ __device__ __forceinline__ void tile_convert(const uint8_t *__restrict__ src, co
 #pragma unroll
             for (int k = 0; k < C::ROUNDS; k++) {
                 const int iy = C::ROUND_ROWS * k + tid / C::ROW_ITEMS;
+#if JPG_ABLATE >= 3
+                *reinterpret_cast<uint32_t *>(&sY[(iy * VS) * C::TW + 4 * ix]) = d[k][0][0] ^ d[k][0][1] ^ d[k][0][2] ^ d[k][VS - 1][0] ^ d[k][VS - 1][1] ^ d[k][VS - 1][2];
+                continue;
+#endif
                 uint32_t y4[VS];
                 float fb[VS][4], fr[VS][4];
                 convert_rows<VS>(d[k], y4, fb, fr);
