@@ -142,7 +142,8 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
         halo_load<HS, VS>(src, g, hmx * 8 * HS, hmy * 8 * VS, lane, halo);
         halo_convert<HS, VS>(src, g, hmx * 8 * HS, hmy * 8 * VS, sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, halo);
         __builtin_amdgcn_wave_barrier();   // (the LDS accesses of one wave execute in order)
-        halo_dc<HS, VS, ALGO>(sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, sHaloDc);
+        if constexpr (ALGO == ALGO_REAL) halo_dc_sums<HS, VS>(sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, sHaloDc);
+        else halo_dc<HS, VS, ALGO>(sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, sHaloDc);
     });
     STAMP(4);
     __syncthreads();
@@ -280,7 +281,8 @@ __global__ __launch_bounds__(64) void k_mcu_dc(const uint8_t *__restrict__ src, 
     halo_load<HS, VS>(src, g, mx * 8 * HS, my * 8 * VS, lane, regs);
     halo_convert<HS, VS>(src, g, mx * 8 * HS, my * 8 * VS, sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, regs);
     __builtin_amdgcn_wave_barrier();   // (the LDS accesses of one wave execute in order)
-    halo_dc<HS, VS, ALGO>(sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, sDc);
+    if constexpr (ALGO == ALGO_REAL) halo_dc_sums<HS, VS>(sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, sDc);
+    else halo_dc<HS, VS, ALGO>(sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, sDc);
     __builtin_amdgcn_wave_barrier();
     if (lane < 3) dc3[lane] = sDc[lane];
 }

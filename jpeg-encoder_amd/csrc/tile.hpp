@@ -375,6 +375,29 @@ __device__ __forceinline__ void halo_dc(const uint8_t *hY, const uint8_t *hCb, c
     dc[lane] = (int16_t)(lane ? transform_dc<ALGO, true>(px) : transform_dc<ALGO, false>(px));
 }
 
+// The same three DC coefficients for the separable real-dct, from sums alone: the DC path of that transform only
+// adds the 64 samples (integers, exact in f32 in any order) before the level shift, the scale and the division
+// (dc_real), so the sum of the block's bytes gives the identical value.  Lanes 16b..16b+15 each take one dword of
+// block b (0 last luma block, 1 Cb, 2 Cr) and add their sums within their row of 16 lanes; dc[0..2] as halo_dc.
+template <int HS, int VS>
+__device__ __forceinline__ void halo_dc_sums(const uint8_t *hY, const uint8_t *hCb, const uint8_t *hCr, int lane, int16_t *dc) {
+    const int b = lane >> 4, j = lane & 15, r = j >> 1, half = j & 1;
+    const uint8_t *p = b == 0 ? hY + (8 * (VS - 1) + r) * 8 * HS + 8 * (HS - 1) + 4 * half
+                              : (b == 1 ? hCb : hCr) + r * 8 + 4 * half;
+    const uint32_t w = lane < 48 ? *reinterpret_cast<const uint32_t *>(p) : 0u;
+    uint32_t sum = __builtin_amdgcn_sad_u8(w, 0u, 0u);                  // the four bytes added up
+    sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x111, 0xf, 0xf, false);  // row_shr:1
+    sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x112, 0xf, 0xf, false);  // row_shr:2
+    sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x114, 0xf, 0xf, false);  // row_shr:4
+    sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x118, 0xf, 0xf, false);  // row_shr:8
+    if (j == 15 && b < 3) {
+        const float s = dct_scale(0, 0) * ((float)sum - 8192.0f);
+        const float q = b == 0 ? (float)quant<false>(0) : (float)quant<true>(0);
+        const float z = b == 0 ? rcp_rn(quant<false>(0)) : rcp_rn(quant<true>(0));
+        dc[b] = (int16_t)(int)div_const(s, q, z);
+    }
+}
+
 // One thread per block: samples from the planes at the start of `lds` into registers, then (the
 // planes' space being reused) the finished blocks to lds[bi * OUT_STRIDE], bi = position of the block
 // in the scan order of the tile.  The last wave also runs spare(); except at 4:2:2 it has no block to transform.
