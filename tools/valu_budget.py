@@ -78,6 +78,8 @@ def static_classes(lines, costs):
             cost = costs[base][0]
         elif re.match(r"v_cvt_f32_ubyte\d", base):
             cost = costs["v_cvt_f32_ubyte0"][0]
+        elif base.startswith("v_pk_") and not base.endswith("_f32") and "v_pk_add_u16" in costs:
+            cost = costs["v_pk_add_u16"][0]                     # packed 16-bit integer forms: one class
         elif base.startswith("v_cmp") or base.startswith("v_cmpx"):
             cost = costs["v_cmp_lt_u32"][0]
         elif base in ("v_mbcnt_lo_u32_b32", "v_mbcnt_hi_u32_b32", "v_readfirstlane_b32", "v_readlane_b32", "v_writelane_b32",
