@@ -77,7 +77,7 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
     __shared__ int16_t sHaloDc[4];                                          // its last Y, Cb, Cr DC coefficients
     __shared__ uint32_t sLut[LUT_WORDS];
     constexpr int WIN_WORDS = win_words<HS, VS>();
-    __shared__ uint32_t sWin[WIN_WORDS + 2];
+    __shared__ __attribute__((aligned(16))) uint32_t sWin[WIN_WORDS + 4];   // (a whole number of 16-byte pieces, for the clearing)
     __shared__ uint32_t sTot[THREADS / 64], sPass[THREADS / 64];
     uint8_t *sY = lds;
     uint8_t *sCb = lds + C::TILE_H * C::TW;
@@ -145,8 +145,9 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
 #endif
 #pragma unroll
     for (int k = 0; k < LUT_ROUNDS; k++)
-        if (tid + k * THREADS < LUT_WORDS) sLut[tid + k * THREADS] = lut_words[k];
-    for (int i = tid; i < WIN_WORDS + 2; i += THREADS) sWin[i] = 0;   // (after the loads, like the table)
+        if ((k + 1) * THREADS <= LUT_WORDS || tid + k * THREADS < LUT_WORDS) sLut[tid + k * THREADS] = lut_words[k];
+    for (int i = tid; i < (WIN_WORDS + 4) / 4; i += THREADS)          // (after the loads, like the table)
+        reinterpret_cast<uint4 *>(sWin)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     STAMP(3);
 #if JPG_ABLATE >= 2   // (timing experiments: the kernel without its later phases; see tools/build_variant.py)

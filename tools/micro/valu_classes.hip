@@ -107,7 +107,12 @@
     X(s_mov_then_4_v_mul_f32, "s_mov_b32 s20, 0x3e991687\n\tv_mul_f32 %0, %0, %2\n\tv_mul_f32 %0, %0, %3\n\tv_mul_f32 %0, %0, %2\n\tv_mul_f32 %0, %0, %3") \
     X(v_readfirstlane_then_v_mul_f32, "v_readfirstlane_b32 s20, %2\n\tv_mul_f32 %0, %0, %2") \
     X(ds_read_b32_then_v_mul_f32, "ds_read_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)\n\tv_mul_f32 %0, %0, %2") \
-    X(s_mov_then_v_cvt, "s_mov_b32 s20, 3\n\tv_cvt_f32_ubyte0 %0, %0")
+    X(s_mov_then_v_cvt, "s_mov_b32 s20, 3\n\tv_cvt_f32_ubyte0 %0, %0") \
+    X(v_mul_f32_sources_in_one_register_bank, "v_mul_f32 v100, v104, v108") \
+    X(v_mul_f32_sources_in_two_register_banks, "v_mul_f32 v100, v105, v110") \
+    X(v_fma_f32_sources_in_one_register_bank, "v_fma_f32 v100, v104, v108, v112") \
+    X(v_fma_f32_sources_in_three_register_banks, "v_fma_f32 v100, v105, v110, v115") \
+    X(v_mul_f32_destination_rotates, "v_mul_f32 %0, v105, v110")
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, u
     case M_##name: {                                                                                            \
         _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                        \
             _Pragma("unroll") for (int i = 0; i < 16; i++)                                                      \
-                asm volatile(text : "+v"(a[i]), "+v"(p[i]) : "v"(c0), "v"(c1), "s"(sg), "v"(pc) : "s20", "s21", "scc");       \
+                asm volatile(text : "+v"(a[i]), "+v"(p[i]) : "v"(c0), "v"(c1), "s"(sg), "v"(pc) : "s20", "s21", "scc", "v100", "v104", "v105", "v108", "v110", "v112", "v115");       \
         }                                                                                                       \
     } break;
             MODES(X)
