@@ -101,7 +101,7 @@ __device__ __forceinline__ uint32_t code_block(const uint16_t *slot, uint32_t ml
     }
     // negative values: v + (1 << size) - 1 (src/jpeg/entropy_coding.rs:140-142)
     uint32_t amp = (uint32_t)(dc_diff < 0 ? dc_diff - 1 : dc_diff) & ((1u << size) - 1u);
-    uint32_t t = lut[256 + size];
+    uint32_t t = lut[(size << 4) | 15];                              // jpgtab::huff_dc_index
     uint32_t bits = (t >> 16) + size;
     w.put(((t & 0xffff) << size) | amp, (t >> 16) + size);
     const uint32_t zrl = lut[0xf0];
