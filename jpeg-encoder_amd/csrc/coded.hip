@@ -146,8 +146,11 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
 #pragma unroll
     for (int k = 0; k < LUT_ROUNDS; k++)
         if ((k + 1) * THREADS <= LUT_WORDS || tid + k * THREADS < LUT_WORDS) sLut[tid + k * THREADS] = lut_words[k];
-    for (int i = tid; i < (WIN_WORDS + 4) / 4; i += THREADS)          // (after the loads, like the table)
-        reinterpret_cast<uint4 *>(sWin)[i] = make_uint4(0, 0, 0, 0);
+    constexpr int WIN_PIECES = (WIN_WORDS + 4) / 4;                    // (cleared after the loads, like the table)
+#pragma unroll
+    for (int r = 0; r < (WIN_PIECES + THREADS - 1) / THREADS; r++)
+        if ((r + 1) * THREADS <= WIN_PIECES || tid + r * THREADS < WIN_PIECES)
+            reinterpret_cast<uint4 *>(sWin)[tid + r * THREADS] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     STAMP(3);
 #if JPG_ABLATE >= 2   // (timing experiments: the kernel without its later phases; see tools/build_variant.py)
@@ -250,10 +253,12 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
         __syncthreads();
         const uint32_t endb = start + pass_bits;
         const uint32_t carry = (endb & 31) ? sWin[endb >> 5] : 0u;
+#pragma unroll 1   // (a tile of photo-like content is one round; unrolled, the loop's set-up costs more than its body)
         for (uint32_t i = tid; i < nwords; i += THREADS) dst[(done >> 5) + i] = sWin[i];
         done += pass_bits;
         if (done >= total) break;
         __syncthreads();
+#pragma unroll 1
         for (uint32_t i = tid; i < nwords + 1; i += THREADS) sWin[i] = i ? 0u : carry;
         __syncthreads();
     }
