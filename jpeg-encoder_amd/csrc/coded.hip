@@ -82,6 +82,10 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
     uint8_t *sY = lds;
     uint8_t *sCb = lds + C::TILE_H * C::TW;
     uint8_t *sCr = sCb + 8 * C::CW;
+#ifdef JPG_PHASE_STAMPS
+    unsigned long long stamp[8];
+    STAMP(0);
+#endif
     // Every kernel argument the workgroup will use is fetched here, in one batch of scalar loads with one wait.  Left to
     // the compiler each is loaded where it is first used, and the start of a workgroup becomes a chain of scalar-load
     // round trips (kernel arguments, then the image's pixel pointer, then the geometry in two pieces: 1500 cycles from
@@ -97,13 +101,11 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
         asm volatile("" : "+s"(g.W), "+s"(g.H), "+s"(g.mcux), "+s"(g.stride), "+s"(g.bottom_up), "+s"(k_row0), "+s"(k_src));
         asm volatile("" : "+s"(k_slot_words), "+s"(k_epoch), "+s"(k_cstride), "+s"(k_clen), "+s"(k_sparse));
     }
-    typedef __attribute__((address_space(1))) uint32_t *global_words;
-    const global_words clen_out = (global_words)k_clen, sparse_out = (global_words)k_sparse;
-#ifdef JPG_PHASE_STAMPS
-    unsigned long long stamp[8];
+#if defined(JPG_PHASE_STAMPS) && defined(JPG_STAMP_AFTER_ARGS)   // the first reading is taken when the arguments have arrived
     STAMP(0);
 #endif
-
+    typedef __attribute__((address_space(1))) uint32_t *global_words;
+    const global_words clen_out = (global_words)k_clen, sparse_out = (global_words)k_sparse;
     // grid: x = tile column, y = MCU row (counted from the first row of the launch: a launch may cover a band of
     // rows, the rows above it being coded by earlier launches), z = image of a batch; no divisions to find the tile
     const int tile_x = blockIdx.x, tile_y = blockIdx.y + k_row0, img = blockIdx.z;
