@@ -269,7 +269,7 @@ __device__ __forceinline__ void tile_convert(const uint8_t *__restrict__ src, co
         if (present) {
 #pragma unroll
             for (int k = 0; k < C::ROUNDS; k++) {
-                const int iy = C::ROUND_ROWS * k + tid / C::ROW_ITEMS;
+                const int iy = C::ROUND_ROWS * k + sub;
 #if JPG_ABLATE >= 3
                 *reinterpret_cast<uint32_t *>(&sY[(iy * VS) * C::TW + 4 * ix]) = d[k][0][0] ^ d[k][0][1] ^ d[k][0][2] ^ d[k][VS - 1][0] ^ d[k][VS - 1][1] ^ d[k][VS - 1][2];
                 continue;
