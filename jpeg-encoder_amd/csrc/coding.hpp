@@ -151,40 +151,32 @@ __device__ __forceinline__ uint32_t halves_nonzero(uint32_t w) {
     return r;
 }
 
-// the low 16 bits of x moved to the even bit positions
-__device__ __forceinline__ uint32_t spread16(uint32_t x) {
-    x = (x | (x << 8)) & 0x00ff00ffu;
-    x = (x | (x << 4)) & 0x0f0f0f0fu;
-    x = (x | (x << 2)) & 0x33333333u;
-    x = (x | (x << 1)) & 0x55555555u;
-    return x;
-}
-
-// acc = 2 * acc + x on both halves of a word at once (written out: the compiler has no pattern for it)
-__device__ __forceinline__ uint32_t halves_shift_in(uint32_t acc, uint32_t x) {
+// acc + lo(flags) * lo(k) + hi(flags) * hi(k): with flags 0/1 in the halves of a word and two powers of two in k,
+// both flags land on their bits of acc in one instruction (written out: the compiler has no pattern for it)
+__device__ __forceinline__ uint32_t flags_place(uint32_t acc, uint32_t flags, uint32_t k) {
     uint32_t r;
-    asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(acc), "v"(x));   // (the low half of the constant for both)
+    asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(flags), "s"(k), "v"(acc));
     return r;
 }
 
-// bit k set where the k-th int16 of the block (8 uint4) is non-zero: per 16 dwords the flags of
-// the low halves are collected in bits 0..15 and those of the high halves in bits 16..31 (one multiply-add per
-// dword, last dword first, shifts the flags in), then the two are interleaved
+// bit k set where the k-th int16 of the block (8 uint4) is non-zero: the block is four groups of eight dwords; dword
+// t of a group holds coefficients 2t and 2t+1 of the group, whose flags go to bits 2t and 2t+1 of the group's 16
+// bits (no interleave: the constant of dword t is 2^(2t) in its low and 2^(2t+1) in its high half)
 __device__ __forceinline__ void nonzero_mask(const uint4 (&q)[8], uint32_t &mlo, uint32_t &mhi) {
-    uint32_t m[2];
+    uint32_t g[4];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < 4; h++) {
         uint32_t f = 0;
 #pragma unroll
-        for (int i = 3; i >= 0; i--) {
-            const uint32_t w[4] = {q[4 * h + i].x, q[4 * h + i].y, q[4 * h + i].z, q[4 * h + i].w};
-#pragma unroll
-            for (int j = 3; j >= 0; j--) f = (i == 3 && j == 3) ? halves_nonzero(w[j]) : halves_shift_in(f, halves_nonzero(w[j]));
+        for (int t = 0; t < 8; t++) {
+            const uint4 &v = q[2 * h + (t >> 2)];
+            const uint32_t w = (t & 3) == 0 ? v.x : ((t & 3) == 1 ? v.y : ((t & 3) == 2 ? v.z : v.w));
+            f = flags_place(f, halves_nonzero(w), (1u << (2 * t)) | (1u << (2 * t + 17)));
         }
-        m[h] = spread16(f & 0xffffu) | (spread16(f >> 16) << 1);
+        g[h] = f;
     }
-    mlo = m[0];
-    mhi = m[1];
+    mlo = g[0] | (g[1] << 16);
+    mhi = g[2] | (g[3] << 16);
 }
 
 // block `jb` of its MCU (0..nb-1): the block before it in the same component's DC chain,
