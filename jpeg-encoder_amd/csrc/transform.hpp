@@ -288,29 +288,175 @@ __device__ __forceinline__ void bin8(int &a0, int &a1, int &a2, int &a3, int &a4
     a7 = x4_2; a5 = x5_2; a3 = x6_2; a1 = x7_2;
 }
 
-template <bool CHROMA>
-__device__ __forceinline__ void transform_bin(const uint32_t (&px)[16], uint32_t *slot) {
-    int a[64];
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-#pragma unroll
-        for (int c = 0; c < 8; c++) a[r * 8 + c] = sample_i(px, r, c);
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        bin8(a[i * 8 + 0], a[i * 8 + 1], a[i * 8 + 2], a[i * 8 + 3], a[i * 8 + 4], a[i * 8 + 5], a[i * 8 + 6],
-             a[i * 8 + 7]);
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        bin8(a[0 * 8 + i], a[1 * 8 + i], a[2 * 8 + i], a[3 * 8 + i], a[4 * 8 + i], a[5 * 8 + i], a[6 * 8 + i],
-             a[7 * 8 + i]);
-    int res[64];
-#pragma unroll
-    for (int n = 0; n < 64; n++) {
-        // i32 / i32 truncating toward zero (src/jpeg/dct_quant.rs:182-186); the
-        // divisor is a compile-time constant, so this is a multiply-high.
-        res[jpgtab::ZZ_OF_NATURAL.k[n]] = a[n] / quant<CHROMA>(n);
+// The same butterfly in f32.  Every value of the transform is an integer far below 2^22, so f32 additions and
+// subtractions are exact; what integer code spends on each lifting step -- a shift-and-add (4 cycles of issue
+// time on a gfx950 SIMD) and an arithmetic shift (2) for floor(k*x/8) -- is one fused multiply-add (2) here: with
+// the f32 rounding mode set to "toward minus infinity", fma(x, k/8, 1.5*2^23) is exactly 1.5*2^23 + floor(k*x/8)
+// (the sum is formed exactly and rounded once, on a grid of whole numbers).  The magic constant is not taken off
+// again: a value travels as n + D*M with D in {-1, 0, +1} (M = 1.5*2^23, all sums still exact), the domain D is
+// part of the type, a multiply-add accepts any domain (its constant absorbs k/8 of the bias) and delivers +M or -M
+// as asked, and the additions are arranged so that the biases cancel: 37 operations per 8 points on biased inputs,
+// 40 or 41 where the results have to be plain.  tools/check_bin_f32.c checks every multiply-add form over its whole
+// input range, the reciprocal quantiser over every dividend and divisor, and the whole transform against the
+// integer code above on random and extreme blocks, on the CPU under the same rounding mode.
+namespace binf {
+constexpr float M = 12582912.0f;   // 1.5 * 2^23: ulp 1 on [2^23, 2^24), room for |n| < 2^22 on either side
+
+template <int D>
+struct V {
+    float v;   // n + D * M
+};
+template <int DA, int DB>
+__device__ __forceinline__ V<DA + DB> operator+(V<DA> a, V<DB> b) {
+    static_assert(DA + DB >= -1 && DA + DB <= 1, "biases must cancel");
+    return {a.v + b.v};
+}
+template <int DA, int DB>
+__device__ __forceinline__ V<DA - DB> operator-(V<DA> a, V<DB> b) {
+    static_assert(DA - DB >= -1 && DA - DB <= 1, "biases must cancel");
+    return {a.v - b.v};
+}
+// floor(NUM * x / 8) + OFF in domain DH (+1 or -1).  Round-toward-minus-infinity must be in force.
+template <int DH, int NUM, int OFF = 0, int DX>
+__device__ __forceinline__ V<DH> fl(V<DX> x) {
+    static_assert(DH == 1 || DH == -1, "the floor needs the magic constant");
+    constexpr float c = NUM / 8.0f;
+    constexpr float K = (float)((double)M * (8 * DH - NUM * DX) / 8.0 + OFF);   // exact: a multiple of 2^19 below 2^25
+    return {__builtin_fmaf(x.v, c, K)};
+}
+template <int D>
+__device__ __forceinline__ V<0> plain(V<D> x) {
+    if constexpr (D == 0) return x;
+    else return {x.v - (float)D * M};
+}
+
+// One 8-point pass (src/jpeg/dct_quant.rs:93-129) on r[0..7], all in domain DI, in place.  OFF: a level shift to
+// take off the inputs on the way (they hold n + OFF; only the four sums see it, the differences cancel it).
+// PLAIN: every result in domain 0; otherwise results 1, 2, 4, 6 stay in domain +1 (row_out_domain).
+template <int DI, int OFF, bool PLAIN>
+__device__ __forceinline__ void bin8f(float &r0, float &r1, float &r2, float &r3, float &r4, float &r5, float &r6, float &r7) {
+    static_assert(DI != 0 || OFF == 0, "a level shift rides on biased inputs only");
+    const V<DI> a0{r0}, a1{r1}, a2{r2}, a3{r3}, a4{r4}, a5{r5}, a6{r6}, a7{r7};
+    const V<0> x7_1 = a0 - a7, x6_1 = a1 - a6, x5_1 = a2 - a5, x4_1 = a3 - a4;
+    // the odd half: x6_1 += 3/8 x5_1; x5_1 = 5/8 x6_1 - x5_1; butterflies; x4_2 -= x7_2/8; x5_2 += 7/8 x6_2; x6_2 -= x5_2/2
+    const V<1> y6 = x6_1 + fl<1, 3>(x5_1);
+    const V<1> y5 = fl<1, 5>(y6) - x5_1;
+    const V<1> x4_2 = x4_1 + y5;
+    const V<-1> x5_2 = x4_1 - y5;
+    const V<-1> x6_2 = x7_1 - y6;
+    const V<1> x7_2 = x7_1 + y6;
+    const V<0> o7 = x4_2 - fl<1, 1>(x7_2);
+    const V<0> o5 = x5_2 + fl<1, 7>(x6_2);
+    const V<0> o3 = x6_2 - fl<-1, 4>(o5);
+    // the even half: x_i_1 = a_i - (x_(7-i)_1 >> 1); butterflies; x0_2 += x1_2; x1_2 = (x0_2 >> 1) - x1_2;
+    // x2_2 -= 3/8 x3_2; x3_2 += 3/8 x2_2
+    if constexpr (DI != 0) {
+        const V<0> x0_1 = a0 - fl<DI, 4, OFF>(x7_1), x1_1 = a1 - fl<DI, 4, OFF>(x6_1);
+        const V<0> x2_1 = a2 - fl<DI, 4, OFF>(x5_1), x3_1 = a3 - fl<DI, 4, OFF>(x4_1);
+        const V<0> e0 = x0_1 + x3_1, e3 = x0_1 - x3_1, e1 = x1_1 + x2_1, e2 = x1_1 - x2_1;
+        const V<0> o0 = e0 + e1;
+        const V<1> o4 = fl<1, 4>(o0) - e1;
+        const V<1> o6 = e2 - fl<-1, 3>(e3);
+        const V<1> o2 = e3 + fl<1, 3>(o6);
+        r0 = o0.v;
+        if constexpr (PLAIN) { r2 = plain(o2).v; r4 = plain(o4).v; r6 = plain(o6).v; }
+        else { r2 = o2.v; r4 = o4.v; r6 = o6.v; }
+    } else {
+        const V<0> x0_1 = plain(a0 - fl<1, 4>(x7_1)), x1_1 = plain(a1 - fl<1, 4>(x6_1));
+        const V<-1> x2_1 = a2 - fl<1, 4>(x5_1);
+        const V<1> x3_1 = a3 - fl<-1, 4>(x4_1);
+        const V<1> e0 = x0_1 + x3_1;
+        const V<-1> e3 = x0_1 - x3_1;
+        const V<-1> e1 = x1_1 + x2_1;
+        const V<1> e2 = x1_1 - x2_1;
+        const V<0> o0 = e0 + e1;
+        const V<0> o4 = fl<-1, 4>(o0) - e1;
+        const V<0> o6 = e2 - fl<1, 3>(e3);
+        const V<0> o2 = e3 + fl<1, 3>(o6);
+        r0 = o0.v; r2 = o2.v; r4 = o4.v; r6 = o6.v;
     }
-    store_zigzag(res, slot);
+    // output order of src/jpeg/dct_quant.rs:122-129
+    r1 = PLAIN ? plain(x7_2).v : x7_2.v;
+    r3 = o3.v; r5 = o5.v; r7 = o7.v;
+}
+// domain of result k of a pass with PLAIN = false
+__device__ __host__ constexpr int row_out_domain(int k) { return (k == 1 || k == 2 || k == 4 || k == 6) ? 1 : 0; }
+
+// The smallest f32 >= 1/q: a * z truncated is a / q (i32 / i32, src/jpeg/dct_quant.rs:182-186) for every
+// |a| <= 2^16 and every divisor of the two tables, whatever the rounding mode of the multiplication.
+__device__ __host__ constexpr float rcp_up(int q) {
+    float z = 1.0f / (float)q;
+    if ((double)z * (double)q < 1.0) z = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, z) + 1u);
+    return z;
+}
+
+// M + byte N of w: a byte placed under the upper bytes of M's bit pattern (0x4B400000) is that sum
+template <int N>
+__device__ __forceinline__ float biased_byte(uint32_t w) {
+    return __uint_as_float(__builtin_amdgcn_perm(0x4b400000u, w, 0x07060500u | (uint32_t)N));
+}
+
+template <bool CHROMA, int V_>
+__device__ __forceinline__ void column_bin(float (&t)[8][8], uint32_t (&w)[32], bool (&seen)[32]) {
+    bin8f<row_out_domain(V_), 0, true>(t[0][V_], t[1][V_], t[2][V_], t[3][V_], t[4][V_], t[5][V_], t[6][V_], t[7][V_]);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = jpgtab::ZZ_OF_NATURAL.k[u * 8 + V_];
+        const float q = t[u][V_] * rcp_up(quant<CHROMA>(u * 8 + V_));
+        if (k & 1) cvt_pack16<1>(w[k >> 1], q, !seen[k >> 1]);
+        else cvt_pack16<0>(w[k >> 1], q, !seen[k >> 1]);
+        seen[k >> 1] = true;
+    }
+}
+}  // namespace binf
+
+// The rounding mode of f32 arithmetic: 0 nearest even (the default everywhere else), 2 toward minus infinity.
+// The instructions that need the mode are tied to the switches by data: the block's samples pass through the
+// first, its finished words through the second, so nothing computed from the one or feeding the other can be
+// scheduled outside.  (Only the two bits of the f32 rounding mode are written.)
+__device__ __forceinline__ void round_down_begin(uint32_t (&p)[16]) {
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\ts_nop 1"
+                 : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(p[8]),
+                   "+v"(p[9]), "+v"(p[10]), "+v"(p[11]), "+v"(p[12]), "+v"(p[13]), "+v"(p[14]), "+v"(p[15]));
+}
+__device__ __forceinline__ void round_down_end(uint32_t (&w)[32]) {
+    asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]),
+                      "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 1"
+                 : "+v"(w[16]), "+v"(w[17]), "+v"(w[18]), "+v"(w[19]), "+v"(w[20]), "+v"(w[21]), "+v"(w[22]), "+v"(w[23]),
+                   "+v"(w[24]), "+v"(w[25]), "+v"(w[26]), "+v"(w[27]), "+v"(w[28]), "+v"(w[29]), "+v"(w[30]), "+v"(w[31])
+                 :
+                 : "memory");
+}
+
+template <bool CHROMA>
+__device__ __forceinline__ void transform_bin(const uint32_t (&px_in)[16], uint32_t *slot) {
+    uint32_t px[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) px[i] = px_in[i];
+    round_down_begin(px);
+    float t[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        // samples as M + byte: domain +1 with the level shift (src/jpeg/dct_quant.rs:63-65) still to come off
+        t[r][0] = binf::biased_byte<0>(px[2 * r]); t[r][1] = binf::biased_byte<1>(px[2 * r]);
+        t[r][2] = binf::biased_byte<2>(px[2 * r]); t[r][3] = binf::biased_byte<3>(px[2 * r]);
+        t[r][4] = binf::biased_byte<0>(px[2 * r + 1]); t[r][5] = binf::biased_byte<1>(px[2 * r + 1]);
+        t[r][6] = binf::biased_byte<2>(px[2 * r + 1]); t[r][7] = binf::biased_byte<3>(px[2 * r + 1]);
+        binf::bin8f<1, 128, false>(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], t[r][5], t[r][6], t[r][7]);
+    }
+    uint32_t w[32];
+    bool seen[32] = {};
+    binf::column_bin<CHROMA, 0>(t, w, seen);
+    binf::column_bin<CHROMA, 1>(t, w, seen);
+    binf::column_bin<CHROMA, 2>(t, w, seen);
+    binf::column_bin<CHROMA, 3>(t, w, seen);
+    binf::column_bin<CHROMA, 4>(t, w, seen);
+    binf::column_bin<CHROMA, 5>(t, w, seen);
+    binf::column_bin<CHROMA, 6>(t, w, seen);
+    binf::column_bin<CHROMA, 7>(t, w, seen);
+    round_down_end(w);
+    store_packed(w, slot);
 }
 
 // --- the DC coefficient alone ------------------------------------------------
