@@ -31,6 +31,11 @@ struct jpg_ctx {
     int16_t *d_coef = nullptr; size_t coef_cap = 0;                            // in blocks
     bool coef_valid = false;    // d_coef holds the coefficients of the current image
     bool two_kernels = false;   // JPG_TWO_KERNELS=1: whole encodes never use the fused coding kernel
+    // The coding kernel's bit window (coded_small_window): 0 chosen per launch from the tile lengths of the encode
+    // finished last, 1 always small, 2 always large (JPG_CODED_WINDOW=small|large)
+    int window_mode = 0;
+    double tile_bits = -1.0;    // mean coded bits per tile of the encode finished last (-1: none yet)
+    int bands_override = 0;     // JPG_BANDS: bands a host-row encode is cut into (0: chosen per image)
     int16_t *d_tmp16 = nullptr; size_t tmp16_cap = 0;
     int16_t *d_dc = nullptr;     // last DCs out (3 values)
     static constexpr int NSLOT = 3;
@@ -45,6 +50,8 @@ struct jpg_ctx {
         hipEvent_t s_done = nullptr;    // stuffing kernel finished (recorded on the stream it ran on)
         bool busy = false;              // s_done has been recorded at least once
         bool dense_valid = false;       // eb.bits holds the dense stream of the last entropy launch
+        bool tiles = false;             // the chunks are tiles of the fused coding kernel
+        bool tail_known = false;        // h_status->last32 is that of the current chunks (k_tail has run on them)
         size_t nblocks = 0;             // blocks of the image the slot's chunks were coded from (sizes the dense stream)
         size_t cap_ticket = 0;
         uint64_t nbits = 0;
@@ -208,6 +215,8 @@ extern "C" int jpg_create(jpg_ctx **out, int device, int dct_algo, int ra, int r
         if (const char *ev = getenv("JPG_STUFF_GRID")) sl.eb.stuff_grid = (size_t)(atoi(ev) > 0 ? atoi(ev) : 0);
     }
     if (const char *ev = getenv("JPG_TWO_KERNELS")) c->two_kernels = atoi(ev) != 0;
+    if (const char *ev = getenv("JPG_CODED_WINDOW")) c->window_mode = !strcmp(ev, "small") ? 1 : (!strcmp(ev, "large") ? 2 : 0);
+    if (const char *ev = getenv("JPG_BANDS")) c->bands_override = atoi(ev) > 0 ? atoi(ev) : 0;
     if (!ok) {
         (void)hipGetLastError();
         jpg_destroy(c);
@@ -276,6 +285,8 @@ bool ratio_factors(int ra, int rb, int rc, int &h, int &v) {
 
 int make_geom(Geom &g, int32_t W, int32_t H, uint32_t stride, int bottom_up, int h, int v) {
     if (W <= 0 || H <= 0 || (uint64_t)stride < (uint64_t)3 * (uint64_t)W) return JPG_ERR_BAD_ARG;
+    // the kernels address the rows of a tile (at most 16) with 32-bit offsets from the tile's lowest row
+    if ((uint64_t)stride * 16 + 4096 >= (1ull << 31)) return JPG_ERR_TOO_LARGE;
     g = Geom{};
     g.W = W; g.H = H; g.h = h; g.v = v;
     g.Wp = round_up(W, 8 * g.h); g.Hp = round_up(H, 8 * g.v);
@@ -606,8 +617,18 @@ static int prepare_slot(jpg_ctx *c, bool coded) {
     sl.eb.epoch++;
     sl.eb.host_status = sl.h_status;
     sl.dense_valid = false;
+    sl.tail_known = false;
+    sl.tiles = coded;
+    // The small bit window while the tiles of the encode before fitted it with room to spare (half of it on average)
+    sl.eb.small_window = coded && coded_small_window(c->g, c->algo) &&
+                         (c->window_mode == 1 || (c->window_mode == 0 && c->tile_bits <= 0.5 * coded_small_window_bits()));
     c->view = c->cur;
     return JPG_OK;
+}
+
+// what the next launch learns from a finished one: the mean length of its tiles
+static void note_tile_bits(jpg_ctx *c, const jpg_ctx::Slot &sl) {
+    if (sl.tiles && sl.eb.nchunks > 0) c->tile_bits = (double)sl.h_status->nbits / (double)sl.eb.nchunks;
 }
 
 static const int16_t ZERO_PRED[3] = {0, 0, 0};   // src/jpeg/entropy_coding.rs:38-40
@@ -695,6 +716,7 @@ static int queue_coding(jpg_ctx *c, const int16_t *pred) {
         if (int e = queue_entropy(c, pred)) return e;
     }
     HIP_TRY(c, launch_tail(S(c).eb, c->stream));
+    S(c).tail_known = true;
     return JPG_OK;
 }
 
@@ -704,6 +726,7 @@ static int finish_coding(jpg_ctx *c, uint64_t *nbits, uint32_t *last32) {
     jpg_ctx::Slot &sl = S(c);
     if (int ke = kernel_error(sl)) return ke;
     sl.nbits = sl.h_status->nbits;
+    note_tile_bits(c, sl);
     if (nbits) *nbits = sl.nbits;
     if (last32) *last32 = sl.h_status->last32;
     c->stage = ST_BITS;
@@ -745,8 +768,21 @@ extern "C" int jpg_entropy_stripe_finish(jpg_ctx *c, uint64_t *nbits, uint32_t *
 
 extern "C" int jpg_stream_tail(jpg_ctx *c, uint32_t *last32) {
     if (!c || !last32) return JPG_ERR_BAD_ARG;
-    if (c->stage < ST_BITS || c->npend || c->code_pending) return JPG_ERR_STATE;
-    *last32 = V(c).h_status->last32;   // left there by the kernel that measured the stream
+    if (c->stage < ST_BITS || c->npend || c->code_pending || c->stitch_pending) return JPG_ERR_STATE;
+    jpg_ctx::Slot &sl = V(c);
+    if ((sl.eb.nimg > 0 ? sl.eb.nimg : 1) != 1) return JPG_ERR_STATE;   // single images only
+    if (!sl.tail_known) {
+        // a whole encode (jpg_encode_device_async, jpg_encode_scan) never measured the tail: do it now, on the
+        // chunks the slot still holds (the stuffing kernel only read them)
+        DeviceGuard dg;
+        if (int e = use_device(c, dg)) return e;
+        if (int e = sync_all(c)) return e;
+        sl.eb.host_status = sl.h_status;
+        HIP_TRY(c, launch_tail(sl.eb, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        sl.tail_known = true;
+    }
+    *last32 = sl.h_status->last32;   // left there by the kernel that measured the stream
     return JPG_OK;
 }
 
@@ -968,7 +1004,7 @@ extern "C" int jpg_stripe_host_async(jpg_ctx *c, const uint8_t *pixels, int32_t 
 // srcs: host array of the batch's device pointers.
 static int queue_encode(jpg_ctx *c, const uint8_t *const *srcs = nullptr, int n = 1) {
     c->cur = (c->cur + 1) % jpg_ctx::NSLOT;
-    if (!c->two_kernels && coded_supported(c->g) && n <= 64) {
+    if (!c->two_kernels && coded_supported(c->g) && n <= MAX_BATCH_IMAGES) {
         if (int e = prepare_slot(c, true)) return e;
         if (int e = launch_timed(c, n, [&](hipEvent_t e0, hipEvent_t e1) {
                 return launch_coded(c->g, c->algo, c->d_src, srcs, n, ZERO_PRED, S(c).eb, c->stream, e0, e1);
@@ -1008,7 +1044,7 @@ extern "C" int jpg_encode_device_async(jpg_ctx *c, const uint8_t *dev_pixels, in
 
 // ---- batches of equally sized images: one launch of each kernel for all of them ----
 
-extern "C" int jpg_max_batch(void) { return 64; }
+extern "C" int jpg_max_batch(void) { return MAX_BATCH_IMAGES; }
 
 extern "C" int jpg_encode_batch_device_async(jpg_ctx *c, const uint8_t *const *dev_pixels, int32_t n, int32_t W, int32_t H,
                                              uint32_t stride, int bottom_up) {
@@ -1073,6 +1109,7 @@ static int report(jpg_ctx *c, int k, uint64_t *nbits, size_t *stuffed_len) {
     if (int ke = kernel_error(sl)) return ke;
     sl.nbits = sl.h_status->nbits;
     sl.scan_len = (size_t)sl.h_status->scan_bytes;
+    note_tile_bits(c, sl);
     if (nbits) *nbits = sl.nbits;
     if (stuffed_len) *stuffed_len = sl.scan_len;
     c->stage = ST_SCAN;
@@ -1104,6 +1141,14 @@ extern "C" int jpg_finish_next(jpg_ctx *c, uint64_t *nbits, size_t *stuffed_len)
     return report(c, k, nbits, stuffed_len);
 }
 
+// A band could not be queued: the bands before it are (copies and kernels that use the caller's rows and the
+// slot), so everything queued is waited for before the error goes back to the caller.
+static int band_failed(jpg_ctx *c, int status) {
+    (void)hipGetLastError();
+    (void)sync_all(c);
+    return status;
+}
+
 // A whole encode of rows in host memory, band by band: the rows of a band of MCU rows are copied on stream_c
 // and the band is coded on `stream` as soon as they have landed, while the following bands are still
 // travelling (a tile needs its own rows and the MCU before it, which lies in its own band or the one above).
@@ -1130,7 +1175,7 @@ static int queue_encode_host_banded(jpg_ctx *c, const uint8_t *pixels, uint32_t 
     // Rows in pageable memory are packed into the staging buffers by the CPU, which is what their time is made
     // of (3.7 ms for the same image): cutting them into bands only adds waits between the chunks (4.1-4.4 ms).
     int nb = !pinned ? 1 : (g.mcuy / 32 < 4 ? g.mcuy / 32 : 4);
-    if (const char *ev = getenv("JPG_BANDS")) nb = atoi(ev);
+    if (c->bands_override) nb = c->bands_override;
     if (nb < 1) nb = 1;
     if (nb > jpg_ctx::MAX_BANDS) nb = jpg_ctx::MAX_BANDS;
     const int per = (g.mcuy + nb - 1) / nb;
@@ -1148,17 +1193,19 @@ static int queue_encode_host_banded(jpg_ctx *c, const uint8_t *pixels, uint32_t 
                 HIP_TRY(c, hipMemcpy2DAsync(dst, pitch, src, host_stride, (size_t)3 * g.W, (size_t)n, hipMemcpyHostToDevice,
                                             cs));
             } else if (int e = copy_rows_staged(c, dst, pitch, src, host_stride, (size_t)3 * g.W, n, cs)) {
-                return e;
+                return band_failed(c, e);
             }
         }
         hipEvent_t &ev = c->band_ev[b];
-        if (!ev) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIP_TRY(c, hipEventRecord(ev, cs));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, ev, 0));
-        if (int e = launch_timed(c, 1, [&](hipEvent_t e0, hipEvent_t e1) {
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return band_failed(c, JPG_ERR_HIP);
+        if (hipEventRecord(ev, cs) != hipSuccess || hipStreamWaitEvent(c->stream, ev, 0) != hipSuccess)
+            return band_failed(c, JPG_ERR_HIP);
+        // (with timing on, the image counts once: its last band carries it, the other launches count no image)
+        const bool last_band = r0 + per >= g.mcuy;
+        if (int e = launch_timed(c, last_band ? 1 : 0, [&](hipEvent_t e0, hipEvent_t e1) {
                 return launch_coded(g, c->algo, c->d_src, nullptr, 1, ZERO_PRED, S(c).eb, c->stream, e0, e1, r0, rows);
             }))
-            return e;
+            return band_failed(c, e);
     }
     c->coef_valid = false;
     c->stage = ST_COEF;

@@ -27,16 +27,23 @@
 namespace jpg {
 
 // LDS words a tile's bits are assembled in per pass: 1536 (48 Kbit; tiles of photo-like content hold about 4 Kbit,
-// noise about 45 Kbit).  (512 words would allow a fifth workgroup per CU: 2 % faster on photo-like content, 23 %
-// slower on noise, whose tiles then take 8 passes; 2048 words is 0.5 % slower than 1536 on both kinds: four
-// workgroups then leave 10 KB of a CU's LDS free instead of 18, room for one instead of two workgroups of the
-// stuffing kernel that runs beside this one.)
+// noise about 45 Kbit).  (2048 words is 0.5 % slower than 1536: four workgroups then leave 10 KB of a CU's LDS free
+// instead of 18, room for one instead of two workgroups of the stuffing kernel that runs beside this one.)
 // At tiles of 1024 pixels (4:2:2, 256 blocks of 144 bytes in LDS) only a window of 256 words leaves room for a
 // fourth workgroup per CU; their tiles hold about 4000 bits on photo-like content, one pass as a rule.
-template <int HS, int VS>
-constexpr int win_words() { return TileCfg<HS, VS>::TW == 1024 ? 256 : 1536; }
+// SMALL: 512 words, with which a workgroup of 512-pixel tiles fits five times into a CU's 160 KB of LDS.  The f32
+// kernels need 100 registers (four waves per SIMD) and gain nothing from it (1 % slower on photo-like content, 16 %
+// on noise).  The integer transform runs in 82 registers since it was rewritten in f32 lifting steps, and a fifth
+// workgroup per CU makes 3840x2160 4:4:4 10 % and 7680x4320 4:2:0 4 % faster on photo-like content -- and noise,
+// whose tiles then take five passes instead of two, 28 % slower.  The caller chooses per launch
+// (EntropyBufs::small_window) from the tile lengths of the encodes before.
+template <int HS, int VS, bool SMALL>
+constexpr int win_words() {
+    return TileCfg<HS, VS>::TW == 1024 ? 256 : (SMALL ? 512 : 1536);
+}
+constexpr int SMALL_WINDOW_BITS = 512 * 32;
 
-constexpr int MAX_LAUNCH_IMAGES = 64;   // images of one launch: their pixel pointers travel in the argument block
+constexpr int MAX_LAUNCH_IMAGES = MAX_BATCH_IMAGES;   // images of one launch: their pixel pointers travel in the argument block
 
 struct CodedArgs {
     // Pixel array of each image of the launch.  In the argument block rather than in memory: the pointer is
@@ -66,7 +73,7 @@ static unsigned long long *g_stamps = nullptr;
 #define STAMP(i)
 #endif
 
-template <int HS, int VS, int ALGO>
+template <int HS, int VS, int ALGO, bool SMALL>
 __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
     using C = TileCfg<HS, VS>;
     constexpr int HV = HS * VS;
@@ -76,7 +83,7 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
     __shared__ __attribute__((aligned(16))) uint8_t sHalo[C::HALO_BYTES];   // planes of the MCU before the tile
     __shared__ int16_t sHaloDc[4];                                          // its last Y, Cb, Cr DC coefficients
     __shared__ uint32_t sLut[LUT_WORDS];
-    constexpr int WIN_WORDS = win_words<HS, VS>();
+    constexpr int WIN_WORDS = win_words<HS, VS, SMALL>();
     __shared__ __attribute__((aligned(16))) uint32_t sWin[WIN_WORDS + 4];   // (a whole number of 16-byte pieces, for the clearing)
     __shared__ uint32_t sTot[THREADS / 64], sPass[THREADS / 64];
     uint8_t *sY = lds;
@@ -283,18 +290,16 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
 extern "C" void jpg_debug_phase_stamps(void *dev_buffer) { g_stamps = static_cast<unsigned long long *>(dev_buffer); }
 #endif
 
-template <int HS, int VS, int ALGO>
+template <int HS, int VS, int ALGO, bool SMALL>
 __global__ __launch_bounds__(THREADS) void k_coded(CodedArgs a) {
-    coded_tile<HS, VS, ALGO>(a);
+    coded_tile<HS, VS, ALGO, SMALL>(a);
 }
 
-// The same kernel held to the 128 registers that let a fourth wave share a SIMD.  The integer transform
-// wants a few more (134); with the cap a handful of values go to scratch memory and the kernel is a tenth faster
-// (3840x2160 4:4:4: 0.83 ms instead of 0.91 ms per 32 images).  Only where LDS leaves room for a fourth
-// workgroup per CU, which the tiles of 1024 pixels (4:2:2) do not.
+// The same kernel held to the 128 registers that let a fourth wave share a SIMD: the f32 transform at tiles of
+// 1024 pixels (4:2:2) wants a few more.
 template <int HS, int VS, int ALGO>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_coded_4waves(CodedArgs a) {
-    coded_tile<HS, VS, ALGO>(a);
+    coded_tile<HS, VS, ALGO, false>(a);
 }
 
 // The DC coefficients of the last Y, Cb, Cr blocks of MCU (mx, my), straight from the pixels: what a
@@ -337,8 +342,8 @@ hipError_t launch_last_dc_pixels(const Geom &g, int algo, const uint8_t *src, in
 }
 
 template <int HS, int VS>
-static hipError_t launch_coded_hv(const CodedArgs &a, int algo, int nimg, int mcu_rows, hipStream_t s, hipEvent_t e0,
-                                  hipEvent_t e1) {
+static hipError_t launch_coded_hv(const CodedArgs &a, int algo, int nimg, int mcu_rows, bool small_window, hipStream_t s,
+                                  hipEvent_t e0, hipEvent_t e1) {
     using C = TileCfg<HS, VS>;
     const int tiles_x = (a.g.mcux + C::MCUS - 1) / C::MCUS;
     const long long tiles = (long long)tiles_x * a.g.mcuy;
@@ -350,12 +355,18 @@ static hipError_t launch_coded_hv(const CodedArgs &a, int algo, int nimg, int mc
     switch (algo) {
         case ALGO_REAL:
             if constexpr (TileCfg<HS, VS>::TW == 1024) hipExtLaunchKernelGGL((k_coded_4waves<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, a);
-            else hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_REAL>), grid, block, 0, s, e0, e1, 0, a);
+            else hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_REAL, false>), grid, block, 0, s, e0, e1, 0, a);
             break;
         case ALGO_BIN:
-            hipExtLaunchKernelGGL((k_coded_4waves<HS, VS, ALGO_BIN>), grid, block, 0, s, e0, e1, 0, a);
+            if constexpr (TileCfg<HS, VS>::TW == 512) {
+                if (small_window) {
+                    hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_BIN, true>), grid, block, 0, s, e0, e1, 0, a);
+                    break;
+                }
+            }
+            hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_BIN, false>), grid, block, 0, s, e0, e1, 0, a);
             break;
-        case ALGO_REAL_STRICT: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_REAL_STRICT>), grid, block, 0, s, e0, e1, 0, a); break;
+        case ALGO_REAL_STRICT: hipExtLaunchKernelGGL((k_coded<HS, VS, ALGO_REAL_STRICT, false>), grid, block, 0, s, e0, e1, 0, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -368,6 +379,10 @@ bool coded_supported(const Geom &g) {
     // slots per segment of the stream, which holds when no two consecutive slots are both nearly empty.
     return g.mcux >= tile_mcus(g);
 }
+
+// the coding kernel of this geometry and transform exists with the small bit window too
+bool coded_small_window(const Geom &g, int algo) { return algo == ALGO_BIN && tile_width(g.h, g.v) == 512; }
+int coded_small_window_bits() { return SMALL_WINDOW_BITS; }
 
 long long coded_tiles(const Geom &g) { return (long long)((g.mcux + tile_mcus(g) - 1) / tile_mcus(g)) * g.mcuy; }
 
@@ -390,9 +405,9 @@ hipError_t launch_coded(const Geom &g, int algo, const uint8_t *src, const uint8
         a.src[i] = srcs ? srcs[i] : src;
         if (!a.src[i] || (reinterpret_cast<uintptr_t>(a.src[i]) & 3)) return hipErrorInvalidValue;   // rows are read as dwords
     }
-    if (g.h == 2 && g.v == 2) return launch_coded_hv<2, 2>(a, algo, nimg, mcu_rows, s, e0, e1);
-    if (g.h == 2 && g.v == 1) return launch_coded_hv<2, 1>(a, algo, nimg, mcu_rows, s, e0, e1);
-    if (g.h == 1 && g.v == 1) return launch_coded_hv<1, 1>(a, algo, nimg, mcu_rows, s, e0, e1);
+    if (g.h == 2 && g.v == 2) return launch_coded_hv<2, 2>(a, algo, nimg, mcu_rows, b.small_window != 0, s, e0, e1);
+    if (g.h == 2 && g.v == 1) return launch_coded_hv<2, 1>(a, algo, nimg, mcu_rows, b.small_window != 0, s, e0, e1);
+    if (g.h == 1 && g.v == 1) return launch_coded_hv<1, 1>(a, algo, nimg, mcu_rows, b.small_window != 0, s, e0, e1);
     return hipErrorInvalidValue;
 }
 

@@ -779,8 +779,9 @@ static hipError_t launch_stream_threads(const EntropyBufs &b, uint64_t bit_offse
     // with eight, 856 K with one for every second CU).
     if (ST_THREADS == ST_THREADS_BATCH && cap > (size_t)resident / 4) cap = (size_t)resident / 4;
     if (b.stuff_grid && b.stuff_grid < cap) cap = b.stuff_grid;
-    if ((size_t)nimg > cap) return hipErrorInvalidValue;       // the caller splits larger batches
-    size_t wpi = cap / nimg;                                     // workgroups per image
+    // workgroups per image; at least one, however many images there are: more workgroups than are resident at once
+    // only queue up (segments are handed out by ticket, so every wait is for a workgroup that is running or done)
+    size_t wpi = cap / nimg > 0 ? cap / nimg : 1;
     if (wpi > b.nseg_cap) wpi = b.nseg_cap ? b.nseg_cap : 1;
     StreamArgs a{b.sparse, b.clen, b.nchunks, ngroups, (int)wpi, b.cstride, (size_t)b.slot_words, out_stride, b.nseg_cap, b.nseg_cap / 64 + 1,
                  b.nseg_cap / 4096 + 1, b.status, (uint32_t)(bit_offset & 7), head_bits, is_last, b.sagg, b.sgrp, b.shyp,
@@ -804,8 +805,5 @@ hipError_t launch_dense(const EntropyBufs &b, hipStream_t s) {
     if ((b.nimg > 0 ? b.nimg : 1) != 1) return hipErrorInvalidValue;   // single images only
     return launch_stream<false>(b, 0, 0, 1, reinterpret_cast<uint8_t *>(b.bits), 0, s);
 }
-
-// most images one launch of the stream kernels can take
-int max_batch_images() { return 128; }
 
 }  // namespace jpg

@@ -41,6 +41,9 @@ constexpr int CHUNK_STRIDE_WORDS = CHUNK_BLOCKS * SLOT_WORDS_PER_BLOCK;
 static_assert(SLOT_WORDS_PER_BLOCK * 32 >= MAX_BLOCK_BITS + 1, "chunk slot too small");
 // byte-stuffing works on segments of this many unstuffed bytes
 constexpr int STUFF_SEG = 4096;
+// images one launch of the coding and stream kernels can take (jpg_max_batch): the pixel pointers of a launch
+// travel in the coding kernel's argument block
+constexpr int MAX_BATCH_IMAGES = 64;
 // groups of 64 chunks a stream reader can tabulate in LDS (52 KiB of LDS; limits an image to 27M blocks)
 constexpr int MAX_GROUPS = 6656;
 
@@ -61,6 +64,7 @@ struct EntropyBufs {
     long long nchunks;     // chunks of one image
     long long cstride;     // chunk slots per image in clen / sparse (nchunks rounded up to 64)
     int slot_words;        // words per chunk slot (blocks per chunk x SLOT_WORDS_PER_BLOCK)
+    int small_window;      // launch_coded: the variant with the small bit window (where coded_small_window() has one)
     uint32_t *clen;        // [nimg][cstride] bits of each chunk
     uint32_t *sparse;      // [nimg][cstride][slot_words] coded bits of each chunk, MSB first in each word
     uint32_t epoch;        // tags the error word of the current entropy launch (host side, 1..2^22)
@@ -103,6 +107,10 @@ hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred
 // coded_slot_words(g) words).  Only for geometries coded_supported() accepts.
 bool coded_supported(const Geom &g);
 long long coded_tiles(const Geom &g);
+// Is there a variant of the coding kernel with a small bit window (a fifth workgroup per CU: faster while the tiles
+// fit the window, slower on content whose tiles are much longer), and how many bits does that window hold?
+bool coded_small_window(const Geom &g, int algo);
+int coded_small_window_bits();
 int coded_slot_words(const Geom &g);
 // mcu_row0 / mcu_rows: the band of MCU rows this launch codes (default: all); the bands of an image are
 // launched in order on one stream, each reading the pixel rows of its own MCU rows and of the one above.
@@ -117,8 +125,6 @@ hipError_t launch_dense(const EntropyBufs &b, hipStream_t s);
 // sums the chunk lengths and picks the last 32 bits of the stream out of the last chunks: status->nbits,
 // status->last32 (and the host copy), without assembling the stream (single images)
 hipError_t launch_tail(const EntropyBufs &b, hipStream_t s);
-// most images one launch of the stream kernels can take
-int max_batch_images();
 
 // JpegImage::new's dimension arithmetic (src/jpeg/jpeg_image.rs:36-56) for chroma factors (h, v): fills g and
 // returns a jpg_status (bad sizes, or the sizes at which the reference skews its chroma plane)

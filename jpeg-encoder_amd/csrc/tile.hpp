@@ -249,6 +249,11 @@ __device__ __forceinline__ void tile_convert(const uint8_t *__restrict__ src, co
                                   (uint32_t)(g.bottom_up ? C::ROUND_ROWS - 1 - sub : sub) * (uint32_t)VS * g.stride;
         const size_t low_row = g.bottom_up ? (size_t)(g.H - y0 - C::TILE_H) : (size_t)y0;
         const uint8_t *tile_base = src + low_row * g.stride + (size_t)3 * x0;
+        // (descriptor word 3 = 0x00020000 is the gfx9-family layout: 32-bit raw data format, no swizzle; make_geom keeps
+        // TILE_H * stride + the widest lane offset below the 2^31 bytes the descriptor covers)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "buffer descriptor and instruction selection of this file are written for gfx950"
+#endif
         const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(tile_base), 0, 0x7fffffff, 0x00020000);
         // row c of the tile (c = VS * ROUND_ROWS * k + r for the first item row of round k) lies c rows above the base
         // in a top-down file and TILE_H - 1 - VS * (ROUND_ROWS - 1) - c rows in a bottom-up one
