@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X JPEG encode path.
 
-    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
+    python bench.py --gpus N --steps K --warmup W [--config 1|2|3|4|5]
 
 Default workload (--config 3): 7680x4320 24-bit BMP rows, 4:2:0, real-dct, the configuration the headline
 metric is quoted on.  One step = every rank encodes `--batch` images (device-resident BMP rows -> stuffed JPEG
@@ -11,7 +11,9 @@ quantisation + Huffman coding (one kernel) and concatenation + byte stuffing (a 
 each per `--per-launch` images, and every image's result is taken before the step's clock stops.  Images are
 independent, so ranks share nothing (weak scaling, no data-path collective).
 
---config 2: 3840x2160 4:4:4 bin-dct, --config 4: 1920x1080 4:2:2 batches: the same loop on those images.
+--config 1: 512x512 4:2:0 real-dct (the reference's CPU-runnable point; the line also carries the oracle's
+per-stage CPU times and the single-image host-to-host latency), --config 2: 3840x2160 4:4:4 bin-dct,
+--config 4: 1920x1080 4:2:2 batches: the same loop on those images.
 --config 5 (--mode stripes): one 32768x32768 4:2:0 image cut into MCU-row stripes, one per rank (strong
 scaling): a step codes the image `--passes` times; per pass the ranks exchange three DC predictors, a bit count
 and a few bits through shared host memory, shift and stuff their piece and copy it device to device into
@@ -19,6 +21,8 @@ rank 0's buffer.
 
 With --gpus N and no WORLD_SIZE in the environment the script starts N processes of itself, one per GPU
 (before anything touches a GPU); under torchrun it is one of the ranks.  Rank 0 prints ONE JSON line.
+The ranks share no data: the only collectives are the barriers around the timed region and the MAX of the
+elapsed times, which travel over a gloo (host) group by default (--control nccl puts them on RCCL).
 """
 import argparse
 import json
@@ -35,6 +39,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 
 # the named configurations (index = position in the list of configurations the metric comes with, 1-based)
 CONFIGS = {
+    1: dict(width=512, height=512, ratio="4:2:0", dct_algorithm="real-dct", mode="batch", resident=512, batch=8192,
+            per_launch=64),
     2: dict(width=3840, height=2160, ratio="4:4:4", dct_algorithm="bin-dct", mode="batch", resident=64, batch=640,
             per_launch=64),
     3: dict(width=7680, height=4320, ratio="4:2:0", dct_algorithm="real-dct", mode="batch", resident=64, batch=640,
@@ -51,7 +57,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
-                    help="named configuration: 2 = 3840x2160 4:4:4 bin-dct, 3 = 7680x4320 4:2:0 real-dct (headline), "
+                    help="named configuration: 1 = 512x512 4:2:0 real-dct (the reference's CPU-runnable point), "
+                         "2 = 3840x2160 4:4:4 bin-dct, 3 = 7680x4320 4:2:0 real-dct (headline), "
                          "4 = batches of 1920x1080 4:2:2, 5 = one 32768x32768 4:2:0 image in MCU-row stripes")
     ap.add_argument("--mode", choices=["batch", "stripes"], default=None)
     ap.add_argument("--width", type=int, default=None)
@@ -76,6 +83,9 @@ def parse():
                     help="take the kernel's own start/end time stamps of every n-th coding-kernel launch of the timed "
                          "region (1 = all of them)")
     ap.add_argument("--noise", action="store_true", help="uniform-noise images (entropy stress)")
+    ap.add_argument("--control", choices=["gloo", "nccl"], default="gloo",
+                    help="what carries the barriers and the MAX of the elapsed times when there are several ranks "
+                         "(no image data ever crosses ranks): a gloo group on the host (default) or RCCL")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--verify", action="store_true",
@@ -140,16 +150,30 @@ def cpu_baseline(args):
         n = max(1, int(33.2e6 / (w * h)))
         what = "%d synthetic image%s of %dx%d" % (n, "s" if n > 1 else "", w, h)
     rows = [J.host.synth_bgr(w, h, seed=1000 + k, noise_only=args.noise) for k in range(n)]
+    stage = {"from_bmp_colour_conversion_1_thread": 0.0, "chrominance_downsampling_2_threads": 0.0,
+             "dct_and_quantization_3_threads": 0.0, "generate_entropy_encoded_data_1_thread": 0.0,
+             "write_image_data_stuffing_1_thread": 0.0}
+    keys = list(stage)
     t0 = time.perf_counter()
     for r in rows:
+        # the thread counts are the reference's: src/jpeg/sampling.rs:83-98 (2), src/jpeg/dct_quant.rs:29-60 (3)
+        ts = [time.perf_counter()]
         im = refcpu.RefImage.from_bgr(r, w, h, r.shape[1], ratio, algo)
+        ts.append(time.perf_counter())
         im.chrominance_downsampling(threads=2)
+        ts.append(time.perf_counter())
         im.dct_and_quantization(cos_mode=refcpu.COS_CALL, threads=3)
+        ts.append(time.perf_counter())
         im.generate_entropy_encoded_data()
+        ts.append(time.perf_counter())
         im.stuffed_scan()
+        ts.append(time.perf_counter())
+        for k in range(5):
+            stage[keys[k]] += ts[k + 1] - ts[k]
     dt = time.perf_counter() - t0
     return {"value": round(n * w * h / 1e6 / dt, 4), "unit": "MP/s", "cores": 3, "kind": "port",
             "sample": "%s, %s %s, pixels already in memory, no file I/O; %.1f s" % (what, args.ratio, args.dct_algorithm, dt),
+            "stage_ms_per_image": {k: round(v / n * 1e3, 3) for k, v in stage.items()},
             "host_cores_available": os.cpu_count()}
 
 
@@ -188,6 +212,30 @@ def e2e_figures(J, args, ratio, device):
     enc.close()
     del pinned
     L.jpg_free(ptr)
+    # file to file with the command-line front end (the reference's own interface): a process of its own, so the
+    # figure includes process start and device initialisation as well as reading the BMP and writing the JPEG
+    cli = os.path.join(ROOT, "jpeg-encoder_amd", "jpeg-encoder")
+    if os.path.exists(cli):
+        import tempfile
+        tmp = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        with tempfile.TemporaryDirectory(dir=tmp) as d:
+            bmp = os.path.join(d, "in.bmp")
+            J.host.write_bmp(bmp, rows, W, H)
+            ts = []
+            for k in range(3):
+                t0 = time.perf_counter()
+                r = subprocess.run([cli, "--image", bmp, "--output", os.path.join(d, "out.jpeg"), "--subsampling-ratio",
+                                    args.ratio, "--dct-algorithm", args.dct_algorithm.replace("-strict", ""), "--fused"],
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                if r.returncode != 0:
+                    ts = []
+                    break
+                ts.append(time.perf_counter() - t0)
+            if ts:
+                out["cli_file_to_file_ms"] = round(min(ts) * 1e3, 1)
+                out["cli_file_to_file"] = round(W * H / min(ts) / 1e6, 1)
+                out["cli_note"] = ("jpeg-encoder --image in.bmp (files in shared memory): process start, device "
+                                   "initialisation, read, encode, write; best of 3")
     return out
 
 
@@ -199,7 +247,7 @@ def pmc_record(workload, kernel):
         try:
             d = json.load(open(p))
             if d.get("workload") == workload and d.get("kernel", "k_front") == kernel and d.get("hbm_bytes_per_launch"):
-                best = d
+                best = dict(d, _file=os.path.relpath(p, ROOT))
         except Exception:
             pass
     return best
@@ -238,8 +286,11 @@ def main():
         raise SystemExit("rank %d needs GPU %d but the node shows %d (BENCH_REHEARSAL_ONE_GPU=1 puts every rank on "
                          "GPU 0 to rehearse the multi-process path)" % (rank, local, ndev))
     torch.cuda.set_device(local)
+    control = "gloo" if rehearsal else args.control
     if world > 1:
-        if rehearsal:
+        # No image data crosses ranks: the group only carries the barriers and the MAX of the elapsed times, and a
+        # host group does that without depending on GPU-to-GPU links.  (--control nccl: the same over RCCL.)
+        if control == "gloo":
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -379,7 +430,7 @@ def main():
         region_images += im
         e.set_timing(0)
     if world > 1:
-        tt = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if control == "gloo" else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
@@ -415,6 +466,12 @@ def main():
         roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": int(traffic * ipl) if traffic else None,
+                # traffic is NOT a measurement of this run: the counters come from a separate rocprofv3 --pmc run
+                # of the same kernel on the same workload (hardware counters cannot be read from inside a run)
+                "traffic_source": ({"file": rec["_file"], "images_per_launch_in_the_counter_run":
+                                    rec.get("images_per_launch_in_the_counter_run"),
+                                    "scaled_to_images_per_launch": ipl, "how": rec.get("command")} if rec else None),
+                "traffic_ratio": round(traffic / alg_image, 4) if traffic else None,
                 "algorithmic_bytes": alg, "kernel_ms": round(rms, 5),
                 "kernel_ms_min": round(st["min"], 5) if st["min"] is not None else None,
                 "kernel_ms_median": round(st["median"], 5) if st["median"] is not None else None,
@@ -493,10 +550,11 @@ def main():
                    "images_per_rank_per_step": args.batch, "resident_images_per_rank": args.resident,
                    "images_per_launch": per_launch, "contexts_per_rank": len(encs),
                    "launch_sets_in_flight_per_context": args.depth, "global_batch": args.batch * world,
-                   "parallelism": "image-sharded x%d" % world, "scan_bytes_last_image": int(scan_len),
+                   "parallelism": "image-sharded x%d" % world, "control_plane": control if world > 1 else None,
+                   "scan_bytes_last_image": int(scan_len),
                    "bits_per_pixel": round(nbits / (W * H), 4)}
             metric = "encode megapixels/sec (%s, device-resident BMP rows -> stuffed JPEG scan)" % (
-                "8K 4:2:0 real-dct" if args.config == 3 and (W, H) == (7680, 4320) else workload)
+                "8K 4:2:0 real-dct" if (W, H, args.ratio, args.dct_algorithm) == (7680, 4320, "4:2:0", "real-dct") else workload)
         out = {
             "metric": metric,
             "value": round(total_mp / dt, 1),

@@ -733,6 +733,14 @@ const int16_t *ref_coeffs(const ref_image *im, int comp, int *w, int *h) {
     if (h) *h = im->co[comp].h;
     return im->co[comp].px;
 }
+/* Test aid without a counterpart in the reference: overwrite the quantised coefficients of one component (same
+ * dimensions, the reference's row-major plane layout), so that generate_entropy_encoded_data can be run on
+ * coefficients that came from elsewhere. */
+int ref_set_coeffs(ref_image *im, int comp, const int16_t *src, int w, int h) {
+    if (!im || !src || comp < 0 || comp > 2 || w != im->co[comp].w || h != im->co[comp].h) return REF_ERR_ARG;
+    memcpy(im->co[comp].px, src, (size_t)w * (size_t)h * sizeof(int16_t));
+    return REF_OK;
+}
 const uint8_t *ref_bits(const ref_image *im, uint64_t *nbits, size_t *nbytes) {
     if (nbits) *nbits = im->bits.nbits;
     if (nbytes) *nbytes = (size_t)((im->bits.nbits + 7) >> 3);

@@ -9,7 +9,7 @@
  * (no cargo/rustc, crates not vendored), and its own tests only pin the block
  * walk order (block_iterator.rs:172-191) and a loose mean-|error|<=1 check on
  * one 8x8 block (dct_quant.rs:242-322).  Those pins are enforced in
- * tests/test_oracle_pins.py.  Everything else (colour conversion, chroma
+ * tests/test_oracle.py.  Everything else (colour conversion, chroma
  * subsampling, run-length/Huffman coding, the zero-bit tail padding that comes
  * from the third-party crate bitvec 1.0.1, byte stuffing, JFIF header bytes)
  * is "parity unpinned": it follows the reference source text only.
@@ -80,6 +80,9 @@ int ref_height(const ref_image *im);
 const uint8_t *ref_plane(const ref_image *im, int comp, int *w, int *h, size_t *len);
 const int16_t *ref_coeffs(const ref_image *im, int comp, int *w, int *h);
 const uint8_t *ref_bits(const ref_image *im, uint64_t *nbits, size_t *nbytes);
+/* test aid (no counterpart in the reference): replace one component's quantised coefficients, w x h as
+ * ref_coeffs reports them, so that the entropy coder can be run on coefficients computed elsewhere */
+int ref_set_coeffs(ref_image *im, int comp, const int16_t *src, int w, int h);
 
 /* BMP reader alone: returns top-down RGB triples (malloc'd, caller frees with ref_free_buf) */
 uint8_t *ref_bmp_load_rgb(const char *path, int32_t *width, int32_t *height, int *err);

@@ -78,6 +78,7 @@ def lib():
     L.ref_plane.restype = u8p
     L.ref_coeffs.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.ref_coeffs.restype = i16p
+    L.ref_set_coeffs.argtypes = [C.c_void_p, C.c_int, i16p, C.c_int, C.c_int]
     L.ref_bits.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
     L.ref_bits.restype = u8p
     L.ref_bmp_load_rgb.argtypes = [C.c_char_p, i32p, i32p, C.POINTER(C.c_int)]
@@ -227,6 +228,14 @@ class RefImage:
         w, h = C.c_int(), C.c_int()
         p = lib().ref_coeffs(self._h, comp, C.byref(w), C.byref(h))
         return np.ctypeslib.as_array(p, (h.value, w.value)).copy()
+
+    def set_coeffs(self, comp, plane):
+        """Replace one component's quantised coefficients (same shape as coeffs(comp))."""
+        a = np.ascontiguousarray(plane, np.int16)
+        e = lib().ref_set_coeffs(self._h, comp, a.ctypes.data_as(C.POINTER(C.c_int16)), a.shape[1], a.shape[0])
+        if e:
+            raise RefError(e)
+        return self
 
     def bits(self):
         nb, ny = C.c_uint64(), C.c_size_t()

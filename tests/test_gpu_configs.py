@@ -1,6 +1,6 @@
 """The named configurations at their full sizes (GPU): byte-exact bin-dct at 3840x2160 4:4:4, the
-coefficient tolerance and PSNR bar at 7680x4320 4:2:0 real-dct, a 1920x1080 4:2:2 batch, and the
-32768x32768 image through stripes."""
+coefficient tolerance and PSNR bar at 7680x4320 4:2:0 real-dct, and a 1920x1080 4:2:2 batch
+(the 32768x32768 image: tests/test_gpu_oracle_links.py)."""
 import io
 import os
 
@@ -127,32 +127,3 @@ def test_config_batch_1920x1080_422(J, oracle, algo, n, per_launch):
             nbits, ln, _ = enc.batch_result(j)
             assert nbits == ref.bits()[1]
             np.testing.assert_array_equal(enc.batch_scan(j), ref.stuffed_scan(), err_msg="image %d" % i)
-
-
-def test_config_gigapixel_stripes(J):
-    """32768x32768, 4:2:0, bin-dct: eight stripes stitched == the image coded whole on one GPU, and
-    un-stuffing the scan gives back the dense stream (no oracle run at this size)."""
-    S = J.stripes
-    tile = J.host.synth_bgr(8192, 4096, seed=(5 << 32))[:, :3 * 8192]
-    rows = np.tile(tile, (8, 4))                                  # 32768 rows of 98304 bytes
-    w = h = 32768
-    assert rows.shape == (h, 3 * w)
-    enc = J.Encoder((4, 2, 0), "bin-dct")
-    whole = enc.encode_scan(rows, w, h)
-    ff = np.nonzero(whole == 0xff)[0]
-    assert (whole[ff + 1] == 0).all()
-    enc.close()
-    n = 8
-    be = J.Encoder((4, 2, 0), "bin-dct")                          # one context takes the stripes in turn
-    plan = S.plan_stripes(h, 2, n)
-    dcs, codes, pieces = [], [], []
-    # phase by phase needs the stripe's coefficients to persist, so keep one context per stripe but
-    # free each after its piece is out: transform+code first (cheap to repeat), place last
-    jobs = [S.StripeJob(J.Encoder((4, 2, 0), "bin-dct"), k, n, rows, w, h, rows.shape[1], 2) for k in range(n)]
-    dcs = [j.transform() for j in jobs]
-    codes = [j.code(dcs) for j in jobs]
-    pieces = [j.place(codes) for j in jobs]
-    got = np.concatenate(pieces)
-    assert got.size == whole.size and np.array_equal(got, whole)
-    assert plan[0] == (0, 4096)
-    be.close()

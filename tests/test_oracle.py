@@ -188,3 +188,23 @@ def test_pillow_decodes(oracle, ratio, algo):
     mse = ((got - src) ** 2).mean()
     psnr = 10 * np.log10(255.0 ** 2 / mse)
     assert psnr > (15.0 if algo == "real-dct" else 8.0), psnr   # (a busy, noisy test image)
+
+
+def test_set_coeffs_feeds_the_entropy_coder(oracle):
+    """The test aid ref_set_coeffs: the entropy coder run on coefficients put back unchanged gives the same bits;
+    with one coefficient changed, different ones; wrong dimensions are refused."""
+    import jpeg_encoder_amd as J
+    rows = J.host.synth_bgr(48, 32, seed=9)
+    a = oracle.RefImage.from_bgr(rows, 48, 32, rows.shape[1], (4, 2, 0), oracle.BIN).encode()
+    b = oracle.RefImage.from_bgr(rows, 48, 32, rows.shape[1], (4, 2, 0), oracle.REAL)
+    b.chrominance_downsampling()
+    for c in range(3):
+        b.set_coeffs(c, a.coeffs(c))
+    b.generate_entropy_encoded_data()
+    assert np.array_equal(a.stuffed_scan(), b.stuffed_scan()) and a.bits()[1] == b.bits()[1]
+    y = a.coeffs(0).copy()
+    y[0, 0] += 3
+    b.set_coeffs(0, y).generate_entropy_encoded_data()
+    assert not np.array_equal(a.bits()[0], b.bits()[0])
+    with pytest.raises(oracle.RefError):
+        b.set_coeffs(1, a.coeffs(0))
