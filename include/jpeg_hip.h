@@ -41,7 +41,9 @@ typedef enum jpg_status {
                                       pushes (Wp/h)*(Hp/v) samples into a plane declared Wc x Hc) */
     JPG_ERR_NOMEM = -10,
     JPG_ERR_CAPACITY = -11,     /* caller buffer too small */
-    JPG_ERR_TOO_LARGE = -12     /* more blocks than the call's kernels index (see the call) */
+    JPG_ERR_TOO_LARGE = -12,    /* more blocks than the call's kernels index (see the call) */
+    JPG_ERR_CHAIN = -13         /* stripe chain: another stripe's values did not arrive in time, or the gather buffer
+                                   is too small for the scan */
 } jpg_status;
 
 /* src/jpeg/dct_quant.rs:8-12.  JPG_DCT_REAL is the separable f32 transform
@@ -239,6 +241,44 @@ int jpg_device_to_host(int device, void *dst, const void *src_dev, size_t bytes)
 int jpg_ipc_export(const void *dev_ptr, uint8_t handle[JPG_IPC_HANDLE_BYTES]);
 int jpg_ipc_open(int device, const uint8_t handle[JPG_IPC_HANDLE_BYTES], void **dev_ptr);
 int jpg_ipc_close(void *dev_ptr);
+
+/* ---- stripe chain: the stripes of one image with every hand-over done by kernels (no counterpart in the
+ * reference; the arithmetic carried is that of src/jpeg/entropy_coding.rs:38-40,149-150, the stuffing after
+ * the shift that of src/jpeg/file.rs:92-103).
+ *
+ * The calls above leave the host between the steps of a stripe (three DC values, a bit count and a few bits, a
+ * stuffed length: a wait and an exchange each).  In a chain the kernels of the ranks publish those values
+ * themselves into a MAILBOX in page-locked host memory that every GPU of the node maps, small one-wave "gate"
+ * kernels queued between the heavy kernels pick them up, and a copy kernel writes the stuffed piece to its byte
+ * offset in the GATHER buffer; the host queues a whole pass at once and waits once.  Every gate wait is bounded
+ * (JPG_CHAIN_TIMEOUT_MS, default 10000) and ends in JPG_ERR_CHAIN, never in a hang.
+ *
+ *  - mailbox: jpg_chain_mailbox_bytes() zeroed bytes the ranks share.  One process driving several GPUs:
+ *    jpg_chain_mailbox_alloc() (release with jpg_free).  One process per GPU: a file in shared memory that every
+ *    rank maps and page-locks with jpg_host_register (jpg_host_unregister before unmapping).
+ *  - gather: where the whole stuffed scan is put together: device memory of the collector rank 0 (the other
+ *    ranks pass the address they reach it by: the same pointer within a process once jpg_peer_access(device,
+ *    owner) returned 1, the result of jpg_ipc_open between processes), or, where GPUs cannot reach each other's
+ *    memory, page-locked / registered host memory.  gather_cap: its size; a scan that does not fit fails the pass.
+ *  - jpg_chain_setup binds both to the context and restarts the pass counter: every rank calls it before the
+ *    first pass, with its rank (0 .. world-1, world <= 64), and all ranks run the same number of passes.
+ *  - jpg_chain_pass_async: after jpg_stripe_device / jpg_stripe_host_async has named the stripe's rows (images
+ *    at least one tile wide: JPG_ERR_STATE otherwise), queues the whole pass on the context's stream and
+ *    returns.  active_mask: bit k set when rank k has a stripe (ranks without rows make no call).
+ *    One process driving several contexts queues the ranks in ascending order (a gate only waits for lower ranks).
+ *  - jpg_chain_pass_finish waits for the context's pass: the stripe's bit count, the length of its stuffed
+ *    piece, where its bits and its piece start, and on rank 0 -- whose pass ends when every piece lies in the
+ *    gather buffer -- the length of the whole scan (0 elsewhere).  Any of the pointers may be NULL. */
+size_t jpg_chain_mailbox_bytes(void);
+void *jpg_chain_mailbox_alloc(void);
+int jpg_host_register(void *p, size_t bytes);
+int jpg_host_unregister(void *p);
+/* 1 when kernels on `device` can write memory of `peer` (peer access is switched on by the call), else 0 */
+int jpg_peer_access(int device, int peer);
+int jpg_chain_setup(jpg_ctx *ctx, int rank, int world, void *mailbox, void *gather, size_t gather_cap);
+int jpg_chain_pass_async(jpg_ctx *ctx, uint64_t active_mask);
+int jpg_chain_pass_finish(jpg_ctx *ctx, uint64_t *nbits, size_t *piece_len, uint64_t *bit_offset, size_t *byte_offset,
+                          size_t *total);
 
 /* ---- an encode that allocates nothing ---------------------------------------
  *

@@ -28,7 +28,7 @@ CXX = os.environ.get("CXX") or shutil.which("g++") or "g++"
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-HIP_SOURCES = ["front.hip", "coded.hip", "staged.hip", "entropy.hip", "api.hip", "static.hip"]
+HIP_SOURCES = ["front.hip", "coded.hip", "staged.hip", "entropy.hip", "api.hip", "static.hip", "chain.hip"]
 HIP_HEADERS = ["internal.hpp", "transform.hpp", "tile.hpp", "coding.hpp", "tables.h", os.path.join(ROOT, "include", "jpeg_hip.h")]
 LIB_HIP = os.path.join(HERE, "libjpeg_hip.so")
 

@@ -93,6 +93,19 @@ struct jpg_ctx {
     bool dc_pending = false;        // jpg_last_dc_async has queued the copy into h_dc
     bool code_pending = false;      // jpg_entropy_stripe_async has queued the coding of the stripe
     bool stitch_pending = false;    // jpg_stitch_async has queued the stuffing of the stripe
+    // stripe chain (jpg_chain_setup): the mailbox all ranks share, where the pieces are gathered, this context's
+    // hand-over record between its gate kernels and the kernels behind them, and the pass counter
+    struct Chain {
+        ChainMail *mail = nullptr;          // device-side address of the mailbox (host memory)
+        uint8_t *gather = nullptr; size_t gather_cap = 0;
+        int rank = 0, world = 0;
+        ChainParams *d_params = nullptr;    // device
+        ChainParams *h_params = nullptr;    // page-locked copy, filled at the end of a pass
+        uint64_t *h_total = nullptr;        // page-locked: the collector's kernel writes the whole scan's length here
+        uint64_t pass = 0;
+        uint64_t timeout_ticks = 0;
+        bool pending = false;
+    } chain;
 };
 
 static inline jpg_ctx::Slot &S(jpg_ctx *c) { return c->slot[c->cur]; }          // being written
@@ -126,6 +139,7 @@ extern "C" const char *jpg_strerror(int st) {
         case JPG_ERR_NOMEM: return "out of memory";
         case JPG_ERR_CAPACITY: return "output buffer too small";
         case JPG_ERR_TOO_LARGE: return "image too large for this path";
+        case JPG_ERR_CHAIN: return "stripe chain: another stripe's values did not arrive in time, or the gather buffer is too small";
     }
     return "unknown status";
 }
@@ -253,6 +267,9 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
         if (c->bounce_done[k]) (void)hipEventDestroy(c->bounce_done[k]);
     }
     if (c->h_dc) (void)hipHostFree(c->h_dc);
+    if (c->chain.d_params) (void)hipFree(c->chain.d_params);
+    if (c->chain.h_params) (void)hipHostFree(c->chain.h_params);
+    if (c->chain.h_total) (void)hipHostFree(c->chain.h_total);
     if (c->scan_host) (void)hipHostFree(c->scan_host);
     for (hipEvent_t e : c->band_ev)
         if (e) (void)hipEventDestroy(e);
@@ -938,6 +955,174 @@ extern "C" int jpg_ipc_close(void *dev_ptr) {
         (void)hipGetLastError();
         return JPG_ERR_HIP;
     }
+    return JPG_OK;
+}
+
+
+// ---- stripe chain: a pass of one stripe with every hand-over between the ranks done by kernels
+
+extern "C" size_t jpg_chain_mailbox_bytes(void) { return CHAIN_MAILBOX_BYTES; }
+
+extern "C" void *jpg_chain_mailbox_alloc(void) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, CHAIN_MAILBOX_BYTES, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    memset(p, 0, CHAIN_MAILBOX_BYTES);
+    return p;
+}
+
+extern "C" int jpg_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return JPG_ERR_BAD_ARG;
+    if (hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        return JPG_ERR_HIP;
+    }
+    return JPG_OK;
+}
+
+extern "C" int jpg_host_unregister(void *p) {
+    if (!p) return JPG_ERR_BAD_ARG;
+    if (hipHostUnregister(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return JPG_ERR_HIP;
+    }
+    return JPG_OK;
+}
+
+extern "C" int jpg_peer_access(int device, int peer) {
+    if (device == peer) return 1;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    if (!can) return 0;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+    bool ok = hipSetDevice(device) == hipSuccess;
+    if (ok) {
+        const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+        ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+    }
+    (void)hipGetLastError();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return ok ? 1 : 0;
+}
+
+// the address the context's device uses for page-locked or registered host memory
+static int device_address_of_host(jpg_ctx *c, void *host, void **dev) {
+    *dev = nullptr;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) {
+        (void)hipGetLastError();
+        *dev = host;   // not known to the runtime as host memory: taken for an address the device reaches as it is
+        return JPG_OK;
+    }
+    if (at.type != hipMemoryTypeHost) { *dev = host; return JPG_OK; }   // device memory (own, a peer's, another process's)
+    HIP_TRY(c, hipHostGetDevicePointer(dev, host, 0));
+    return JPG_OK;
+}
+
+extern "C" int jpg_chain_setup(jpg_ctx *c, int rank, int world, void *mailbox, void *gather, size_t gather_cap) {
+    if (!c || !mailbox || !gather || world < 1 || world > CHAIN_MAX_RANKS || rank < 0 || rank >= world) return JPG_ERR_BAD_ARG;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    if (int e = sync_all(c)) return e;
+    jpg_ctx::Chain &ch = c->chain;
+    void *mail_dev = nullptr, *gather_dev = nullptr;
+    if (int e = device_address_of_host(c, mailbox, &mail_dev)) return e;
+    if (int e = device_address_of_host(c, gather, &gather_dev)) return e;
+    if (!ch.d_params) HIP_TRY(c, hipMalloc((void **)&ch.d_params, sizeof(ChainParams)));
+    if (!ch.h_params) HIP_TRY(c, hipHostMalloc((void **)&ch.h_params, sizeof(ChainParams), hipHostMallocDefault));
+    if (!ch.h_total) HIP_TRY(c, hipHostMalloc((void **)&ch.h_total, sizeof(uint64_t), hipHostMallocDefault));
+    HIP_TRY(c, hipMemset(ch.d_params, 0, sizeof(ChainParams)));
+    memset(ch.h_params, 0, sizeof(ChainParams));
+    *ch.h_total = 0;
+    ch.mail = static_cast<ChainMail *>(mail_dev);
+    ch.gather = static_cast<uint8_t *>(gather_dev);
+    ch.gather_cap = gather_cap;
+    ch.rank = rank; ch.world = world;
+    ch.pass = 0;
+    ch.pending = false;
+    // how long a gate waits for another rank before the pass fails (wall clock of the device, 100 MHz)
+    long ms = 10000;
+    if (const char *ev = getenv("JPG_CHAIN_TIMEOUT_MS")) ms = atol(ev) > 0 ? atol(ev) : ms;
+    ch.timeout_ticks = (uint64_t)ms * 100000ull;
+    return JPG_OK;
+}
+
+extern "C" int jpg_chain_pass_async(jpg_ctx *c, uint64_t active_mask) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    jpg_ctx::Chain &ch = c->chain;
+    if (!ch.mail) return JPG_ERR_STATE;
+    if (c->stage < ST_COEF || ch.pending || !code_from_rows(c)) return JPG_ERR_STATE;   // a loaded stripe the coding kernel takes
+    if (!((active_mask >> ch.rank) & 1)) return JPG_ERR_BAD_ARG;
+    if (ch.world < 64 && (active_mask >> ch.world)) return JPG_ERR_BAD_ARG;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    c->npend = 0;
+    if (int e = prepare_slot(c, true)) return e;
+    jpg_ctx::Slot &sl = S(c);
+    int pred_rank = -1, last_rank = ch.rank;
+    for (int k = 0; k < ch.world; k++) {
+        if (!((active_mask >> k) & 1)) continue;
+        if (k < ch.rank) pred_rank = k;
+        last_rank = k > last_rank ? k : last_rank;
+    }
+    const uint64_t pass = ch.pass++;
+    const ChainPass cp{ch.mail, ch.d_params, sl.eb.status, sl.eb.epoch, 0x8000u | (uint32_t)(pass & 0x7fff), (int)(pass & 1),
+                       ch.rank, pred_rank, active_mask, ch.timeout_ticks};
+    // the stripe's last DC coefficients (straight from its last MCU's pixels), published; the predecessor's fetched
+    HIP_TRY(c, launch_last_dc_pixels(c->g, c->algo, c->d_src, c->d_dc, c->stream));
+    HIP_TRY(c, launch_chain_pred(cp, c->d_dc, c->stream));
+    sl.eb.chain = ch.d_params;
+    sl.eb.chain_slot = ch.mail + cp.parity * CHAIN_MAX_RANKS + ch.rank;
+    sl.eb.chain_tag = cp.tag;
+    int e = launch_timed(c, 1, [&](hipEvent_t e0, hipEvent_t e1) {
+        return launch_coded(c->g, c->algo, c->d_src, nullptr, 1, ZERO_PRED, sl.eb, c->stream, e0, e1);
+    });
+    hipError_t he = hipSuccess;
+    if (!e) {
+        he = launch_tail(sl.eb, c->stream);                    // bit count and last bits, published
+        sl.tail_known = he == hipSuccess;
+        if (he == hipSuccess) he = launch_chain_place(cp, c->stream);
+    }
+    if (!e && he == hipSuccess) e = queue_stuff(c, 0, 0, ch.rank == last_rank, c->stream);   // shift and head bits from the gate
+    sl.eb.chain = nullptr; sl.eb.chain_slot = nullptr; sl.eb.chain_tag = 0;
+    if (e) return e;
+    HIP_TRY(c, he);
+    HIP_TRY(c, launch_chain_offset(cp, ch.gather_cap, c->stream));
+    HIP_TRY(c, launch_chain_copy(cp, sl.eb.scan, ch.gather, c->stream));
+    HIP_TRY(c, launch_chain_done(cp, ch.rank == 0 ? ch.h_total : nullptr, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(ch.h_params, ch.d_params, sizeof(ChainParams), hipMemcpyDeviceToHost, c->stream));
+    ch.pending = true;
+    return JPG_OK;
+}
+
+extern "C" int jpg_chain_pass_finish(jpg_ctx *c, uint64_t *nbits, size_t *piece_len, uint64_t *bit_offset, size_t *byte_offset,
+                                     size_t *total) {
+    if (!c) return JPG_ERR_BAD_ARG;
+    jpg_ctx::Chain &ch = c->chain;
+    if (!ch.pending) return JPG_ERR_STATE;
+    DeviceGuard dg;
+    if (int e = use_device(c, dg)) return e;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    ch.pending = false;
+    jpg_ctx::Slot &sl = S(c);
+    if (int ke = kernel_error(sl)) return ke;
+    sl.nbits = sl.h_status->nbits;
+    sl.scan_len = (size_t)sl.h_status->scan_bytes;
+    note_tile_bits(c, sl);
+    c->stage = ST_SCAN;
+    if (ch.h_params->failed) return JPG_ERR_CHAIN;
+    if (ch.rank == 0 && (*ch.h_total >> 63)) return JPG_ERR_CHAIN;
+    if (nbits) *nbits = sl.nbits;
+    if (piece_len) *piece_len = sl.scan_len;
+    if (bit_offset) *bit_offset = ch.h_params->bit_offset;
+    if (byte_offset) *byte_offset = (size_t)ch.h_params->byte_offset;
+    if (total) *total = ch.rank == 0 ? (size_t)(*ch.h_total & ~(1ull << 63)) : 0;
     return JPG_OK;
 }
 

@@ -1,0 +1,228 @@
+// Stripe chain: the kernels that carry the scalars linking the MCU-row stripes of one image from GPU to GPU.
+//
+// The reference codes an image serially (src/jpeg/entropy_coding.rs:16-125); cut between MCU rows, a stripe needs
+// from the stripes above it the three DC predictors (src/jpeg/entropy_coding.rs:38-40,149-150), their bit counts,
+// the bits that share its first byte, and -- because 0xFF stuffing (src/jpeg/file.rs:92-103) follows the shift --
+// their stuffed lengths.  Each value is published by a kernel of the rank that computed it into a mailbox in
+// page-locked host memory that all GPUs of the node map, and picked up by a small "gate" kernel queued in front of
+// the kernel that needs it: a gate is one wave that polls, leaves the values in the context's ChainParams and ends,
+// so the heavy kernels never wait themselves and a waiting rank holds one wave slot, not a grid.  Every wait is
+// bounded (wall clock) and ends in an error, never in a hang.
+#include "../../include/jpeg_hip.h"
+
+#include "internal.hpp"
+
+namespace jpg {
+
+namespace {
+
+constexpr uint64_t VALUE_MASK = (1ull << 48) - 1;
+constexpr uint64_t DONE_ERROR = 1ull << 47;
+
+__device__ __forceinline__ uint64_t mail_pack(uint32_t tag, uint64_t value) { return ((uint64_t)tag << 48) | (value & VALUE_MASK); }
+
+// the mailbox lies in host memory shared by several GPUs (and processes): system scope
+__device__ __forceinline__ void mail_store(uint64_t *p, uint64_t w) {
+    __hip_atomic_store(p, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint64_t mail_load(const uint64_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Poll *p until it carries `tag` (lanes with need == false do not poll); all lanes of the wave leave together.
+// Returns the value, or 0 with `timeout` set when the clock ran out.
+__device__ __forceinline__ uint64_t mail_wait(const uint64_t *p, bool need, uint32_t tag, uint64_t timeout_ticks, bool &timeout) {
+    uint64_t w = 0;
+    bool ok = !need;
+    const uint64_t t0 = wall_clock64();
+    for (uint32_t spin = 0;; spin++) {
+        if (!ok) {
+            w = mail_load(p);
+            ok = (w >> 48) == tag;
+        }
+        if (__ballot(!ok) == 0) break;
+        if ((spin & 15) == 15 && wall_clock64() - t0 > timeout_ticks) { timeout = true; break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return need && ok ? (w & VALUE_MASK) : 0;
+}
+
+__device__ __forceinline__ void chain_fail(const ChainPass &c) {
+    c.params->failed = 1;
+    atomicMin(&c.status->error, -(int)((c.err_epoch << 8) | (uint32_t)(-JPG_ERR_CHAIN)));
+}
+
+__global__ __launch_bounds__(64) void k_chain_pred(ChainPass c, const int16_t *dc3) {
+    const int lane = threadIdx.x;
+    ChainMail *box = c.mail + c.parity * CHAIN_MAX_RANKS;
+    if (lane == 0) {
+        c.params->failed = 0;
+        if (dc3) {
+            const uint64_t v = ((uint64_t)(uint16_t)dc3[0] << 32) | ((uint64_t)(uint16_t)dc3[1] << 16) | (uint16_t)dc3[2];
+            mail_store(&box[c.rank].dc, mail_pack(c.tag, v));
+        }
+    }
+    bool timeout = false;
+    const bool need = lane == 0 && c.pred_rank >= 0;
+    const uint64_t v = mail_wait(&box[need ? c.pred_rank : 0].dc, need, c.tag, c.timeout_ticks, timeout);
+    if (lane == 0) {
+        c.params->pred[0] = (int16_t)(v >> 32);       // src/jpeg/entropy_coding.rs:38-40: zero without a predecessor
+        c.params->pred[1] = (int16_t)(v >> 16);
+        c.params->pred[2] = (int16_t)v;
+        c.params->pred[3] = 0;
+    }
+    if (__ballot(timeout) && lane == 0) chain_fail(c);
+}
+
+// lane k looks after rank k
+__global__ __launch_bounds__(64) void k_chain_place(ChainPass c) {
+    __shared__ uint64_t sBits[CHAIN_MAX_RANKS];
+    __shared__ uint32_t sTail[CHAIN_MAX_RANKS];
+    const int lane = threadIdx.x;
+    const ChainMail *box = c.mail + c.parity * CHAIN_MAX_RANKS;
+    const bool need = lane < c.rank && ((c.active >> lane) & 1);
+    bool timeout = false;
+    sBits[lane] = mail_wait(&box[lane].bits, need, c.tag, c.timeout_ticks, timeout);
+    sTail[lane] = (uint32_t)mail_wait(&box[lane].tail, need, c.tag, c.timeout_ticks, timeout);
+    __syncthreads();
+    if (lane == 0) {
+        // where this stripe's bits start, and the last 32 bits of everything before it (stripes may be a few bits long)
+        uint64_t total = 0;
+        uint32_t last = 0;
+        for (int k = 0; k < c.rank; k++) {
+            const uint64_t n = sBits[k];
+            if (!n) continue;
+            last = n >= 32 ? sTail[k] : ((last << n) | sTail[k]);
+            total += n;
+        }
+        const uint32_t r = (uint32_t)(total & 7);
+        c.params->bit_offset = total;
+        c.params->shift = r;
+        c.params->head = r ? ((last & ((1u << r) - 1u)) << (8 - r)) & 0xffu : 0u;
+    }
+    if (__ballot(timeout) && lane == 0) chain_fail(c);
+}
+
+__global__ __launch_bounds__(64) void k_chain_offset(ChainPass c, unsigned long long gather_cap) {
+    __shared__ uint64_t sLen[CHAIN_MAX_RANKS];
+    const int lane = threadIdx.x;
+    ChainMail *box = c.mail + c.parity * CHAIN_MAX_RANKS;
+    const uint64_t own = c.status->scan_bytes;
+    if (lane == 0) mail_store(&box[c.rank].len, mail_pack(c.tag, own));
+    const bool need = lane < c.rank && ((c.active >> lane) & 1);
+    bool timeout = false;
+    sLen[lane] = mail_wait(&box[lane].len, need, c.tag, c.timeout_ticks, timeout);
+    const bool timed_out = __ballot(timeout) != 0;
+    __syncthreads();
+    if (lane == 0) {
+        uint64_t off = 0;
+        for (int k = 0; k < c.rank; k++) off += sLen[k];
+        const bool bad = timed_out || c.params->failed || off + own > gather_cap;
+        c.params->byte_offset = off;
+        c.params->len = bad ? 0 : own;
+        if (bad) chain_fail(c);
+    }
+}
+
+// dst may have any alignment (it follows the pieces before it): 16-byte stores on its aligned part, each put together
+// from the source dwords around it; single bytes at both ends.
+__global__ __launch_bounds__(256) void k_chain_copy(const ChainParams *params, const uint8_t *__restrict__ src,
+                                                     uint8_t *__restrict__ gather) {
+    const uint64_t len = params->len;
+    if (!len) return;
+    uint8_t *dst = gather + params->byte_offset;
+    const uint64_t head = min((uint64_t)((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15), len);
+    const uint64_t body = (len - head) / 16;                     // 16-byte pieces
+    const uint64_t tail0 = head + body * 16;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (uint64_t)gridDim.x * blockDim.x;
+    if (t < head) dst[t] = src[t];
+    if (t < len - tail0) dst[tail0 + t] = src[tail0 + t];
+    // source of piece i starts at src + head + 16 i: dword index and byte phase (src itself is 16-byte aligned)
+    const uint32_t *sw = reinterpret_cast<const uint32_t *>(src);
+    const uint32_t phase = (uint32_t)(head & 3) * 8;
+    const uint64_t w0 = head >> 2;
+    uint4 *dv = reinterpret_cast<uint4 *>(dst + head);
+    for (uint64_t i = t; i < body; i += nt) {
+        const uint64_t w = w0 + 4 * i;
+        uint32_t a[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) a[k] = sw[w + k];          // (the buffer is padded beyond len: the fifth read stays inside)
+        uint4 o;
+        o.x = phase ? __builtin_amdgcn_alignbit(a[1], a[0], phase) : a[0];
+        o.y = phase ? __builtin_amdgcn_alignbit(a[2], a[1], phase) : a[1];
+        o.z = phase ? __builtin_amdgcn_alignbit(a[3], a[2], phase) : a[2];
+        o.w = phase ? __builtin_amdgcn_alignbit(a[4], a[3], phase) : a[3];
+        dv[i] = o;
+    }
+    __threadfence_system();
+}
+
+__global__ __launch_bounds__(64) void k_chain_done(ChainPass c, uint64_t *host_total) {
+    __shared__ uint64_t sDone[CHAIN_MAX_RANKS];
+    const int lane = threadIdx.x;
+    ChainMail *box = c.mail + c.parity * CHAIN_MAX_RANKS;
+    if (lane == 0) {
+        __threadfence_system();
+        mail_store(&box[c.rank].done, mail_pack(c.tag, (c.params->failed ? DONE_ERROR : 0) | c.params->len));
+    }
+    if (c.rank != 0) return;
+    // collector: every piece has landed when every rank with a stripe has said so
+    const bool need = ((c.active >> lane) & 1) != 0;
+    bool timeout = false;
+    sDone[lane] = mail_wait(&box[lane].done, need, c.tag, c.timeout_ticks, timeout);
+    bool bad = __ballot(timeout) != 0;
+    __syncthreads();
+    if (lane == 0) {
+        uint64_t total = 0;
+        for (int k = 0; k < CHAIN_MAX_RANKS; k++) {
+            bad = bad || (sDone[k] & DONE_ERROR);
+            total += sDone[k] & (DONE_ERROR - 1);
+        }
+        if (bad) chain_fail(c);
+        c.params->total = total;
+        if (host_total) {
+            *host_total = total | (bad ? (1ull << 63) : 0);
+            __threadfence_system();
+        }
+    }
+}
+
+bool pass_ok(const ChainPass &c) {
+    return c.mail && c.params && c.status && c.rank >= 0 && c.rank < CHAIN_MAX_RANKS && c.pred_rank < c.rank &&
+           (c.parity == 0 || c.parity == 1) && (c.tag & 0x8000u) && c.tag <= 0xffffu;
+}
+
+}  // namespace
+
+hipError_t launch_chain_pred(const ChainPass &c, const int16_t *dc3, hipStream_t s) {
+    if (!pass_ok(c)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_chain_pred, dim3(1), dim3(64), 0, s, c, dc3);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain_place(const ChainPass &c, hipStream_t s) {
+    if (!pass_ok(c)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_chain_place, dim3(1), dim3(64), 0, s, c);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain_offset(const ChainPass &c, size_t gather_cap, hipStream_t s) {
+    if (!pass_ok(c)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_chain_offset, dim3(1), dim3(64), 0, s, c, (unsigned long long)gather_cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain_copy(const ChainPass &c, const uint8_t *scan, uint8_t *gather, hipStream_t s) {
+    if (!pass_ok(c) || !scan || !gather || (reinterpret_cast<uintptr_t>(scan) & 15)) return hipErrorInvalidValue;
+    // enough workgroups to keep a few hundred 16-byte stores in flight per CU; the loop covers any length
+    hipLaunchKernelGGL(k_chain_copy, dim3(2048), dim3(256), 0, s, c.params, scan, gather);
+    return hipGetLastError();
+}
+
+hipError_t launch_chain_done(const ChainPass &c, uint64_t *host_total, hipStream_t s) {
+    if (!pass_ok(c)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_chain_done, dim3(1), dim3(64), 0, s, c, host_total);
+    return hipGetLastError();
+}
+
+}  // namespace jpg

@@ -52,6 +52,7 @@ struct CodedArgs {
     Geom g;
     int mcu_row0;                 // first MCU row of this launch (0 unless the image is coded band by band)
     int16_t pred[3];              // DC predictors the first MCU of every image starts from
+    const int16_t *pred_dev;      // ... read from here instead when not null (a stripe whose predictors a kernel queued before this one fetched)
     uint32_t epoch;               // tags errors (see raise_error)
     long long cstride;            // tile slots per image in clen / sparse
     int slot_words;               // words per tile slot
@@ -169,7 +170,7 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
     tile_transform<HS, VS, ALGO>(lds, mcus, tid, [&] {
         if (!has_halo) {
             // first tile of the image: the caller's predictors, left where the coders look for the MCU before the tile
-            if (lane < 3) sHaloDc[lane] = lane == 0 ? a.pred[0] : (lane == 1 ? a.pred[1] : a.pred[2]);
+            if (lane < 3) sHaloDc[lane] = a.pred_dev ? a.pred_dev[lane] : (lane == 0 ? a.pred[0] : (lane == 1 ? a.pred[1] : a.pred[2]));
             return;
         }
         HaloRegs<VS> halo;
@@ -397,7 +398,8 @@ hipError_t launch_coded(const Geom &g, int algo, const uint8_t *src, const uint8
     if (!srcs) nimg = 1;
     if ((g.stride & 3) || nimg < 1 || nimg > MAX_LAUNCH_IMAGES || !coded_supported(g)) return hipErrorInvalidValue;
     if (nimg != (b.nimg > 0 ? b.nimg : 1) || b.nchunks != coded_tiles(g)) return hipErrorInvalidValue;
-    CodedArgs a{{}, g, mcu_row0, {pred[0], pred[1], pred[2]}, b.epoch, b.cstride, b.slot_words, b.clen, b.sparse, b.status};
+    CodedArgs a{{}, g, mcu_row0, {pred[0], pred[1], pred[2]}, b.chain ? b.chain->pred : nullptr, b.epoch, b.cstride, b.slot_words,
+                b.clen, b.sparse, b.status};
 #ifdef JPG_PHASE_STAMPS
     a.stamps = g_stamps;
 #endif

@@ -313,6 +313,7 @@ struct StreamArgs {
     DevStatus *status;       // [nimg] nbits, scan_bytes and tail out
     uint32_t shift;          // place the stream `shift` (0..7) bits later
     uint32_t head;           // bits OR-ed into the first byte (top `shift` bits)
+    const ChainParams *chain;   // both are read from here instead when not null (left there by a kernel queued before this one)
     int is_last;             // keep the trailing partial byte
     uint64_t *agg, *grp, *hyp;  // three-level sums of 0xFF counts per segment
     uint32_t *ticket;        // [nimg][2] next segment to hand out, workgroups that have left (both 0 between launches)
@@ -384,6 +385,10 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     constexpr int DIRECT_ITEMS = ST_THREADS;      // segments whose predecessors' counts are read directly, one per thread
     constexpr int GATHER_ROUNDS = (DENSE_WORDS + 2 * 132 + ST_THREADS - 1) / ST_THREADS;
     static_assert(SEG_WORDS == WPT * ST_THREADS && ST_THREADS >= TABLE, "whole words per thread");
+    if (a.chain) {
+        a.shift = a.chain->shift;
+        a.head = a.chain->head;
+    }
     {   // this workgroup's image: from here on `a` describes that image alone
         const int img = blockIdx.x / a.wpi;
         a.sparse += (size_t)img * a.cstride * a.slot_words;
@@ -683,8 +688,10 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 // (where their bits start, and the bits that share a byte with their first ones) before anything is
 // assembled.  One workgroup: a 64-bit sum of the chunk lengths, then one thread walks back from the last
 // chunk until it has 32 bits.
+// chain_slot: where a stripe of a chain publishes both for the stripes after it (host memory shared by the GPUs).
 __global__ __launch_bounds__(256) void k_tail(const uint32_t *__restrict__ sparse, const uint32_t *__restrict__ clen,
-                                              long long nchunks, size_t slot_words, DevStatus *status, DevStatus *host_status) {
+                                              long long nchunks, size_t slot_words, DevStatus *status, DevStatus *host_status,
+                                              ChainMail *chain_slot, uint32_t chain_tag) {
     __shared__ uint64_t sSum[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint64_t sum = 0;
@@ -708,12 +715,17 @@ __global__ __launch_bounds__(256) void k_tail(const uint32_t *__restrict__ spars
     status->nbits = nbits;
     status->last32 = acc;
     if (host_status) *host_status = *status;
+    if (chain_slot) {
+        __hip_atomic_store(&chain_slot->tail, ((uint64_t)chain_tag << 48) | acc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&chain_slot->bits, ((uint64_t)chain_tag << 48) | (nbits & ((1ull << 48) - 1)), __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 hipError_t launch_tail(const EntropyBufs &b, hipStream_t s) {
     if ((b.nimg > 0 ? b.nimg : 1) != 1 || b.slot_words <= 0) return hipErrorInvalidValue;   // single images only
     hipLaunchKernelGGL(k_tail, dim3(1), dim3(256), 0, s, b.sparse, b.clen, b.nchunks, (size_t)b.slot_words, b.status,
-                       b.host_status);
+                       b.host_status, b.chain_slot, b.chain_tag);
     return hipGetLastError();
 }
 
@@ -784,7 +796,7 @@ static hipError_t launch_stream_threads(const EntropyBufs &b, uint64_t bit_offse
     size_t wpi = cap / nimg > 0 ? cap / nimg : 1;
     if (wpi > b.nseg_cap) wpi = b.nseg_cap ? b.nseg_cap : 1;
     StreamArgs a{b.sparse, b.clen, b.nchunks, ngroups, (int)wpi, b.cstride, (size_t)b.slot_words, out_stride, b.nseg_cap, b.nseg_cap / 64 + 1,
-                 b.nseg_cap / 4096 + 1, b.status, (uint32_t)(bit_offset & 7), head_bits, is_last, b.sagg, b.sgrp, b.shyp,
+                 b.nseg_cap / 4096 + 1, b.status, (uint32_t)(bit_offset & 7), head_bits, STUFF ? b.chain : nullptr, is_last, b.sagg, b.sgrp, b.shyp,
                  b.sticket, b.stuff_epoch, b.epoch, out, b.host_status, b.trace};
     hipLaunchKernelGGL((k_stream<STUFF, ST_THREADS>), dim3((unsigned)(wpi * nimg)), dim3(ST_THREADS), lds, s, a);
     return hipGetLastError();

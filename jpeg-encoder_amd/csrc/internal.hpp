@@ -57,6 +57,37 @@ struct DevStatus {
     uint32_t reserved;
 };
 
+// ---- stripe chain: one image cut into MCU-row stripes, one per GPU, whose kernels hand each other the few
+// scalars that link neighbouring stripes (the three DC predictors of src/jpeg/entropy_coding.rs:38-40,149-150,
+// the bit counts that fix where a stripe's bits start, the bits that share a byte, the stuffed lengths that fix
+// where a piece lies) through a mailbox in page-locked host memory that every GPU of the node reads and writes
+// directly: no host thread takes part between the first and the last kernel of a pass.
+constexpr int CHAIN_MAX_RANKS = 64;
+// One record per (parity of the pass number, rank), written only by kernels of that rank.  Every word is
+// {tag:16 | value:48} and stored whole; tag = 0x8000 | (pass & 0x7fff), so a zeroed mailbox and the words of
+// two passes ago (same parity) never look valid.
+struct ChainMail {
+    uint64_t dc;     // value = y:16 | cb:16 | cr:16, the DC coefficients of the stripe's last Y, Cb, Cr blocks
+    uint64_t bits;   // bits of the stripe's unstuffed stream
+    uint64_t tail;   // its last min(32, bits) bits, right-aligned
+    uint64_t len;    // bytes of its stuffed piece
+    uint64_t done;   // the piece lies in the gather buffer: value = error:1 (bit 47) | bytes:47
+    uint64_t pad[3];
+};
+static_assert(sizeof(ChainMail) == 64, "one record per 64 bytes");
+constexpr size_t CHAIN_MAILBOX_BYTES = 2 * CHAIN_MAX_RANKS * sizeof(ChainMail);
+// What the gate kernels of a context leave for the kernels queued behind them (device memory of the context).
+struct ChainParams {
+    int16_t pred[4];        // DC predictors the stripe starts from
+    uint32_t shift, head;   // bit offset of the stripe modulo 8; the bits before it in its first byte, top-aligned
+    uint64_t bit_offset;    // of the stripe in the whole scan
+    uint64_t byte_offset;   // of its stuffed piece in the gather buffer
+    uint64_t len;           // bytes the copy kernel moves (0 after a failure)
+    uint64_t total;         // collector rank: bytes of the whole scan
+    uint32_t failed;        // a wait ran out, or the gather buffer is too small
+    uint32_t pad;
+};
+
 // A "chunk" is the unit whose bits one kernel assembles on its own: 64 consecutive blocks
 // (k_entropy) or the blocks of one tile of the fused encoder (k_coded).
 struct EntropyBufs {
@@ -84,7 +115,38 @@ struct EntropyBufs {
     size_t scan_stride;    // bytes per image
     size_t nseg_cap;       // stuffing segments an image can have
     unsigned long long *trace;  // debug builds only (JPG_TRACE): phase stamps of the stream kernel
+    // stripe chain (all null / 0 otherwise)
+    const ChainParams *chain;   // launch_coded takes the DC predictors, launch_stuff the shift and head bits from here
+    ChainMail *chain_slot;      // launch_tail publishes the stripe's bit count and last bits here, tagged chain_tag
+    uint32_t chain_tag;
 };
+
+// One pass of a stripe through the chain, as the launchers below need it
+struct ChainPass {
+    ChainMail *mail;            // [2][CHAIN_MAX_RANKS], host memory visible to every GPU
+    ChainParams *params;        // this context's
+    DevStatus *status;          // this context's status record of the pass (errors are raised here)
+    uint32_t err_epoch;         // ... tagged with this
+    uint32_t tag;               // 0x8000 | (pass & 0x7fff)
+    int parity;                 // pass & 1
+    int rank;
+    int pred_rank;              // last rank before this one with a stripe of its own, -1: none
+    uint64_t active;            // bit k: rank k has a stripe
+    uint64_t timeout_ticks;     // of the 100 MHz clock: how long a gate waits for another rank
+};
+// first kernel of a pass: clears params->failed, publishes dc3[0..2] (device memory: the DC coefficients of this
+// stripe's last blocks), then waits for the predecessor's -> params->pred
+hipError_t launch_chain_pred(const ChainPass &c, const int16_t *dc3, hipStream_t s);
+// gate: wait for bit count and last bits of every earlier stripe -> params->shift / head / bit_offset
+hipError_t launch_chain_place(const ChainPass &c, hipStream_t s);
+// publishes the piece's length (status->scan_bytes), waits for the earlier pieces' -> params->byte_offset / len
+hipError_t launch_chain_offset(const ChainPass &c, size_t gather_cap, hipStream_t s);
+// copies params->len bytes of `scan` to gather + params->byte_offset (any alignment; peer or host memory)
+hipError_t launch_chain_copy(const ChainPass &c, const uint8_t *scan, uint8_t *gather, hipStream_t s);
+// publishes "piece in place"; on the collector rank (rank 0) also waits for every rank's and writes the total
+// to params->total and *host_total (page-locked), bit 63 set when any rank failed
+hipError_t launch_chain_done(const ChainPass &c, uint64_t *host_total, hipStream_t s);
+
 
 // e0/e1: optional events that receive the kernel's own start and end time stamps.
 // srcs/nimg: a batch of nimg equally sized images (device array of device pointers) in one launch;

@@ -141,6 +141,20 @@ class Encoder:
         """Queue the copy of the stuffed piece to device memory (a peer copy when dst_device is another GPU)."""
         self._ck(self._L.jpg_scan_copy_to_device(self._ctx, dst_ptr, dst_device, cap))
 
+    # ---- stripe chain: a whole pass of the stripe queued at once, the ranks' kernels hand the scalars on themselves
+    def chain_setup(self, rank, world, mailbox_ptr, gather_ptr, gather_cap):
+        self._ck(self._L.jpg_chain_setup(self._ctx, rank, world, mailbox_ptr, gather_ptr, gather_cap))
+
+    def chain_pass_async(self, active_mask):
+        self._ck(self._L.jpg_chain_pass_async(self._ctx, active_mask))
+
+    def chain_pass_finish(self):
+        """(bits of the stripe, bytes of its stuffed piece, bit offset, byte offset, bytes of the whole scan on rank 0)."""
+        nbits, off = C.c_uint64(), C.c_uint64()
+        n, boff, total = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._ck(self._L.jpg_chain_pass_finish(self._ctx, C.byref(nbits), C.byref(n), C.byref(off), C.byref(boff), C.byref(total)))
+        return nbits.value, n.value, off.value, boff.value, total.value
+
     # ---- fused path ------------------------------------------------------
     def front_device(self, dev_ptr, width, height, stride, bottom_up=True):
         self.width, self.height = width, height

@@ -80,6 +80,39 @@
     X(v_not_b32, "v_not_b32 %0, %0") \
     X(v_mov_b64, "v_mov_b64 %1, %5") \
     X(v_cndmask_b32_vcc_set_once, "v_cndmask_b32 %0, %0, %2, vcc") \
+    X(v_cndmask_b32_sgpr_pair_mask, "v_cndmask_b32 %0, %0, %2, s[22:23]") \
+    X(v_cmp_then_v_cndmask_b32_vcc, "v_cmp_lt_u32 vcc, %0, %2\n\tv_cndmask_b32 %0, %0, %3, vcc") \
+    X(v_dot2_u32_u16, "v_dot2_u32_u16 %0, %0, %2, %3") \
+    X(v_readfirstlane_b32, "v_readfirstlane_b32 s20, %0") \
+    X(v_readlane_b32, "v_readlane_b32 s20, %0, 3") \
+    X(v_writelane_b32, "v_writelane_b32 %0, s22, 3") \
+    X(v_mbcnt_lo_u32_b32, "v_mbcnt_lo_u32_b32 %0, %2, %0") \
+    X(v_mbcnt_hi_u32_b32, "v_mbcnt_hi_u32_b32 %0, %2, %0") \
+    X(v_xad_u32, "v_xad_u32 %0, %0, %2, %3") \
+    X(v_bfe_i32, "v_bfe_i32 %0, %0, 8, 8") \
+    X(v_lshrrev_b64, "v_lshrrev_b64 %1, 3, %1") \
+    X(v_max_u32, "v_max_u32 %0, %0, %2") \
+    X(v_max3_u32, "v_max3_u32 %0, %0, %2, %3") \
+    X(v_min_i32, "v_min_i32 %0, %0, %2") \
+    X(v_min_f32, "v_min_f32 %0, %0, %2") \
+    X(v_rcp_iflag_f32, "v_rcp_iflag_f32 %0, %0") \
+    X(v_sub_u16, "v_sub_u16 %0, %0, %2") \
+    X(v_lshlrev_b16, "v_lshlrev_b16 %0, 3, %0") \
+    X(v_lshrrev_b16, "v_lshrrev_b16 %0, 3, %0") \
+    X(v_ashrrev_i16, "v_ashrrev_i16 %0, 3, %0") \
+    X(v_add_u16, "v_add_u16 %0, %0, %2") \
+    X(v_mul_lo_u16, "v_mul_lo_u16 %0, %0, %2") \
+    X(v_mad_u16, "v_mad_u16 %0, %0, %2, %3") \
+    X(v_mul_i32_i24, "v_mul_i32_i24 %0, %0, %2") \
+    X(v_mad_i32_i24, "v_mad_i32_i24 %0, %0, %2, %3") \
+    X(v_nop, "v_nop") \
+    X(v_pk_add_u16_op_sel, "v_pk_add_u16 %0, %0, %2 op_sel:[1,0] op_sel_hi:[0,1]") \
+    X(v_pk_sub_i16, "v_pk_sub_i16 %0, %0, %2") \
+    X(v_pk_lshlrev_b16, "v_pk_lshlrev_b16 %0, 3, %0") \
+    X(v_pk_mad_i16, "v_pk_mad_i16 %0, %0, %2, %3") \
+    X(v_cvt_f32_f16, "v_cvt_f32_f16 %0, %0") \
+    X(v_cvt_pk_i16_i32, "v_cvt_pk_i16_i32 %0, %0, %2") \
+    X(v_cvt_pknorm_i16_f32, "v_cvt_pknorm_i16_f32 %0, %0, %2") \
     X(v_bitop3_b32, "v_bitop3_b32 %0, %0, %2, %3 bitop3:0x6c") \
     X(v_add_lshl_u32, "v_add_lshl_u32 %0, %0, %2, 2") \
     X(v_lshl_add_u64, "v_lshl_add_u64 %1, %1, 0, %5") \
@@ -132,6 +165,10 @@ __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, u
     const float c0 = seed * 0.5f + 0.00001f * threadIdx.x, c1 = seed + 0.25f;
     const f2 pc = (f2){c0, c1};
     const float sg = __builtin_amdgcn_readfirstlane(seed + 3.0f);
+    // the masks the select modes read: set here, once; the instruction streams below name vcc and s[22:23] as
+    // clobbered, so the compiler keeps nothing of its own in them
+    asm volatile("s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x33333333\n\ts_mov_b32 s22, 0x0f0f0f0f\n\ts_mov_b32 s23, 0x55555555"
+                 ::: "vcc", "s22", "s23");
     __syncthreads();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -141,7 +178,7 @@ __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, u
     case M_##name: {                                                                                            \
         _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                        \
             _Pragma("unroll") for (int i = 0; i < 16; i++)                                                      \
-                asm volatile(text : "+v"(a[i]), "+v"(p[i]) : "v"(c0), "v"(c1), "s"(sg), "v"(pc) : "s20", "s21", "scc", "v100", "v104", "v105", "v108", "v110", "v112", "v115");       \
+                asm volatile(text : "+v"(a[i]), "+v"(p[i]) : "v"(c0), "v"(c1), "s"(sg), "v"(pc) : "s20", "s21", "s22", "s23", "vcc", "scc", "v100", "v104", "v105", "v108", "v110", "v112", "v115");       \
         }                                                                                                       \
     } break;
             MODES(X)
