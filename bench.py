@@ -86,6 +86,14 @@ def parse():
     ap.add_argument("--control", choices=["gloo", "nccl"], default="gloo",
                     help="what carries the barriers and the MAX of the elapsed times when there are several ranks "
                          "(no image data ever crosses ranks): a gloo group on the host (default) or RCCL")
+    ap.add_argument("--stripe-protocol", choices=["chain", "host"], default="chain",
+                    help="stripes mode: 'chain' = the ranks' kernels hand each other the DC predictors, bit counts and "
+                         "stuffed lengths through a mailbox in host memory and copy their pieces to their byte offsets "
+                         "(a pass is queued at once, one wait); 'host' = the host exchanges those values between the "
+                         "steps (four waits per pass)")
+    ap.add_argument("--gather", choices=["auto", "device", "host"], default="auto",
+                    help="stripes mode, chain protocol: where the pieces meet: rank 0's device memory opened by the "
+                         "other ranks through an inter-process handle, or shared host memory (the fallback of 'auto')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--verify", action="store_true",
@@ -342,15 +350,36 @@ def main():
                 def close(self):
                     pass
             ex = _Solo()
-        gather = S.DeviceGather(J._native, local)
         ptr = dev_rows.data_ptr() if hs > 0 else None
+        chain = gather = None
+        if args.stripe_protocol == "chain":
+            # room for the whole stuffed scan: half a byte per pixel (photo-like content needs a tenth of that,
+            # uniform noise a bit over a quarter byte)
+            chain = S.StripeChain(enc, ex, W * H // 2 + (1 << 20), gather=args.gather)
 
-        def step():
-            for _ in range(args.passes):
-                last[0] = S.encode_striped(enc, None, W, H, stride, vs, True, exchange=ex, gather=gather, fetch=False,
-                                           stripe_ptr=ptr)
+            queued = [0]
+
+            def step():
+                # up to two passes are queued before the first is taken: the host queues a pass while the one before
+                # it runs (also across steps; drain() takes what is left before the clock is read)
+                for _ in range(args.passes):
+                    if queued[0] == 2:
+                        last[0] = chain.finish()
+                        queued[0] -= 1
+                    if chain.encode_async(W, H, stride, vs, stripe_ptr=ptr):
+                        queued[0] += 1
+        else:
+            gather = S.DeviceGather(J._native, local)
+
+            def step():
+                for _ in range(args.passes):
+                    last[0] = S.encode_striped(enc, None, W, H, stride, vs, True, exchange=ex, gather=gather, fetch=False,
+                                               stripe_ptr=ptr)
 
         def drain():
+            while chain and queued[0]:
+                last[0] = chain.finish()
+                queued[0] -= 1
             return last[0]
         launches_per_step = args.passes
         images_per_step = args.passes
@@ -540,7 +569,11 @@ def main():
             cfg = {"workload": "%dx%d BMP, %s, %s, MCU-row stripes" % (W, H, args.ratio, args.dct_algorithm),
                    "named_config": args.config, "encodes_of_the_image_per_step": args.passes,
                    "stripes": world, "stripe_rows_rank0": J.stripes.plan_stripes(H, vs, world)[0][1],
-                   "parallelism": "MCU-row stripes x%d, scalars through shared host memory, pieces by device-to-device copy" % world,
+                   "stripe_protocol": args.stripe_protocol, "gather": chain.gather if chain else "device",
+                   "passes_in_flight": 2 if chain else 1, "control_plane": control if world > 1 else None,
+                   "parallelism": ("MCU-row stripes x%d, scalars handed on by the kernels through a mailbox in host memory, "
+                                   "pieces copied to their offsets by a kernel" if chain else
+                                   "MCU-row stripes x%d, scalars through shared host memory, pieces by device-to-device copy") % world,
                    "scan_bytes": int(result)}
             metric = "encode megapixels/sec (%dx%d %s %s in MCU-row stripes, device-resident BMP rows -> stitched stuffed scan on rank 0's GPU)" % (
                 W, H, args.ratio, args.dct_algorithm)
@@ -590,13 +623,13 @@ def main():
             whole = np.concatenate([synth_stripe(k)[:plan[k][1] - plan[k][0]] for k in reversed(range(world))])   # bottom-up file
             ref = J.Encoder(ratio, args.dct_algorithm, device=local)
             want = ref.encode_scan(whole, W, H, stride)
-            got = gather.read(int(result))
+            got = (chain or gather).read(int(result))
             ref.close()
             if not np.array_equal(got, want):
                 raise SystemExit("stitched scan differs from the whole-image encode")
             print("verified: %d stitched bytes equal the whole-image scan" % got.size, file=sys.stderr, flush=True)
+        (chain or gather).close()
         ex.close()
-        gather.close()
     if world > 1:
         dist.destroy_process_group()
 

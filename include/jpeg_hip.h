@@ -253,9 +253,10 @@ int jpg_ipc_close(void *dev_ptr);
  * offset in the GATHER buffer; the host queues a whole pass at once and waits once.  Every gate wait is bounded
  * (JPG_CHAIN_TIMEOUT_MS, default 10000) and ends in JPG_ERR_CHAIN, never in a hang.
  *
- *  - mailbox: jpg_chain_mailbox_bytes() zeroed bytes the ranks share.  One process driving several GPUs:
- *    jpg_chain_mailbox_alloc() (release with jpg_free).  One process per GPU: a file in shared memory that every
- *    rank maps and page-locks with jpg_host_register (jpg_host_unregister before unmapping).
+ *  - mailbox: jpg_chain_mailbox_alloc(): jpg_chain_mailbox_bytes() zeroed bytes of page-locked host memory the
+ *    ranks share (release with jpg_free).  One process driving several GPUs passes the pointer to every
+ *    context; with one process per GPU rank 0 allocates and exports it (jpg_ipc_export works on page-locked host
+ *    memory of jpg_host_alloc / jpg_chain_mailbox_alloc as on device memory) and the others jpg_ipc_open it.
  *  - gather: where the whole stuffed scan is put together: device memory of the collector rank 0 (the other
  *    ranks pass the address they reach it by: the same pointer within a process once jpg_peer_access(device,
  *    owner) returned 1, the result of jpg_ipc_open between processes), or, where GPUs cannot reach each other's
@@ -266,13 +267,13 @@ int jpg_ipc_close(void *dev_ptr);
  *    at least one tile wide: JPG_ERR_STATE otherwise), queues the whole pass on the context's stream and
  *    returns.  active_mask: bit k set when rank k has a stripe (ranks without rows make no call).
  *    One process driving several contexts queues the ranks in ascending order (a gate only waits for lower ranks).
- *  - jpg_chain_pass_finish waits for the context's pass: the stripe's bit count, the length of its stuffed
+ *    Two passes may be queued before the first is taken (the host queues one while the other runs); a third is
+ *    refused with JPG_ERR_STATE.
+ *  - jpg_chain_pass_finish waits for the context's oldest queued pass: the stripe's bit count, the length of its stuffed
  *    piece, where its bits and its piece start, and on rank 0 -- whose pass ends when every piece lies in the
  *    gather buffer -- the length of the whole scan (0 elsewhere).  Any of the pointers may be NULL. */
 size_t jpg_chain_mailbox_bytes(void);
 void *jpg_chain_mailbox_alloc(void);
-int jpg_host_register(void *p, size_t bytes);
-int jpg_host_unregister(void *p);
 /* 1 when kernels on `device` can write memory of `peer` (peer access is switched on by the call), else 0 */
 int jpg_peer_access(int device, int peer);
 int jpg_chain_setup(jpg_ctx *ctx, int rank, int world, void *mailbox, void *gather, size_t gather_cap);

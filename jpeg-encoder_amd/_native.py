@@ -27,7 +27,7 @@ SYMBOLS = [
     "jpg_device_to_host", "jpg_ipc_export", "jpg_ipc_open", "jpg_ipc_close",
     "jpg_encode_scan_begin", "jpg_encode_scan_end",
     "jpg_static_init", "jpg_static_scan_capacity", "jpg_encode_device_static", "jpg_static_status",
-    "jpg_chain_mailbox_bytes", "jpg_chain_mailbox_alloc", "jpg_host_register", "jpg_host_unregister", "jpg_peer_access",
+    "jpg_chain_mailbox_bytes", "jpg_chain_mailbox_alloc", "jpg_peer_access",
     "jpg_chain_setup", "jpg_chain_pass_async", "jpg_chain_pass_finish",
 ]
 STATIC_SCRATCH_BYTES = 24 << 20
@@ -154,8 +154,6 @@ def lib():
     L.jpg_chain_mailbox_bytes.restype = C.c_size_t
     L.jpg_chain_mailbox_alloc.argtypes = []
     L.jpg_chain_mailbox_alloc.restype = vp
-    L.jpg_host_register.argtypes = [vp, C.c_size_t]
-    L.jpg_host_unregister.argtypes = [vp]
     L.jpg_peer_access.argtypes = [C.c_int, C.c_int]
     L.jpg_chain_setup.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_size_t]
     L.jpg_chain_pass_async.argtypes = [vp, C.c_uint64]

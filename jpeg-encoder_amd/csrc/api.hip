@@ -46,6 +46,7 @@ struct jpg_ctx {
         const uint8_t **d_srcs = nullptr; size_t cap_srcs = 0;   // device array of a batch's pixel pointers
         size_t cap_clen = 0, cap_sparse = 0, cap_scan = 0, cap_status = 0, cap_sagg = 0, cap_sgrp = 0, cap_shyp = 0;
         DevStatus *h_status = nullptr;  // [cap_status] pinned copy of eb.status
+        DevStatus *h_status_alt = nullptr;   // not owned: where the kernels of the launches being queued put the copy instead
         hipEvent_t e_done = nullptr;    // entropy kernel finished (recorded on stream)
         hipEvent_t s_done = nullptr;    // stuffing kernel finished (recorded on the stream it ran on)
         bool busy = false;              // s_done has been recorded at least once
@@ -100,11 +101,17 @@ struct jpg_ctx {
         uint8_t *gather = nullptr; size_t gather_cap = 0;
         int rank = 0, world = 0;
         ChainParams *d_params = nullptr;    // device
-        ChainParams *h_params = nullptr;    // page-locked copy, filled at the end of a pass
-        uint64_t *h_total = nullptr;        // page-locked: the collector's kernel writes the whole scan's length here
-        uint64_t pass = 0;
+        // Two passes may be queued before the first is taken: the page-locked records a pass reports through exist
+        // twice, indexed by the parity of the pass number
+        ChainParams *h_params = nullptr;    // [2] copies of d_params, made at the end of a pass
+        uint64_t *h_total = nullptr;        // [2] the collector's last kernel writes the whole scan's length here
+        DevStatus *h_status = nullptr;      // [2] status records of the passes
+        hipEvent_t ev[2] = {nullptr, nullptr};   // end of a pass
+        uint32_t epoch_of[2] = {0, 0};      // epoch the pass's errors are tagged with
+        long long nchunks_of[2] = {0, 0};
+        uint64_t pass = 0;                  // passes queued
+        uint64_t taken = 0;                 // passes whose results have been handed out
         uint64_t timeout_ticks = 0;
-        bool pending = false;
     } chain;
 };
 
@@ -270,6 +277,9 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
     if (c->chain.d_params) (void)hipFree(c->chain.d_params);
     if (c->chain.h_params) (void)hipHostFree(c->chain.h_params);
     if (c->chain.h_total) (void)hipHostFree(c->chain.h_total);
+    if (c->chain.h_status) (void)hipHostFree(c->chain.h_status);
+    for (hipEvent_t e : c->chain.ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->scan_host) (void)hipHostFree(c->scan_host);
     for (hipEvent_t e : c->band_ev)
         if (e) (void)hipEventDestroy(e);
@@ -632,7 +642,7 @@ static int prepare_slot(jpg_ctx *c, bool coded) {
         sl.eb.epoch = 0;
     }
     sl.eb.epoch++;
-    sl.eb.host_status = sl.h_status;
+    sl.eb.host_status = sl.h_status_alt ? sl.h_status_alt : sl.h_status;
     sl.dense_valid = false;
     sl.tail_known = false;
     sl.tiles = coded;
@@ -672,7 +682,7 @@ static int queue_stuff(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, int i
         sl.eb.stuff_epoch = 0;
     }
     sl.eb.stuff_epoch++;
-    sl.eb.host_status = sl.h_status;
+    sl.eb.host_status = sl.h_status_alt ? sl.h_status_alt : sl.h_status;
     HIP_TRY(c, launch_stuff(sl.eb, bit_offset, head_bits, is_last, st));
     HIP_TRY(c, hipEventRecord(sl.s_done, st));
     sl.busy = true;
@@ -973,24 +983,6 @@ extern "C" void *jpg_chain_mailbox_alloc(void) {
     return p;
 }
 
-extern "C" int jpg_host_register(void *p, size_t bytes) {
-    if (!p || !bytes) return JPG_ERR_BAD_ARG;
-    if (hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
-        (void)hipGetLastError();
-        return JPG_ERR_HIP;
-    }
-    return JPG_OK;
-}
-
-extern "C" int jpg_host_unregister(void *p) {
-    if (!p) return JPG_ERR_BAD_ARG;
-    if (hipHostUnregister(p) != hipSuccess) {
-        (void)hipGetLastError();
-        return JPG_ERR_HIP;
-    }
-    return JPG_OK;
-}
-
 extern "C" int jpg_peer_access(int device, int peer) {
     if (device == peer) return 1;
     int can = 0;
@@ -1021,7 +1013,11 @@ static int device_address_of_host(jpg_ctx *c, void *host, void **dev) {
         return JPG_OK;
     }
     if (at.type != hipMemoryTypeHost) { *dev = host; return JPG_OK; }   // device memory (own, a peer's, another process's)
-    HIP_TRY(c, hipHostGetDevicePointer(dev, host, 0));
+    if (hipHostGetDevicePointer(dev, host, 0) != hipSuccess || !*dev) {
+        (void)hipGetLastError();
+        *dev = host;   // (memory of another process opened through a handle: one address for host and devices)
+    }
+    (void)c;
     return JPG_OK;
 }
 
@@ -1035,17 +1031,21 @@ extern "C" int jpg_chain_setup(jpg_ctx *c, int rank, int world, void *mailbox, v
     if (int e = device_address_of_host(c, mailbox, &mail_dev)) return e;
     if (int e = device_address_of_host(c, gather, &gather_dev)) return e;
     if (!ch.d_params) HIP_TRY(c, hipMalloc((void **)&ch.d_params, sizeof(ChainParams)));
-    if (!ch.h_params) HIP_TRY(c, hipHostMalloc((void **)&ch.h_params, sizeof(ChainParams), hipHostMallocDefault));
-    if (!ch.h_total) HIP_TRY(c, hipHostMalloc((void **)&ch.h_total, sizeof(uint64_t), hipHostMallocDefault));
+    if (!ch.h_params) HIP_TRY(c, hipHostMalloc((void **)&ch.h_params, 2 * sizeof(ChainParams), hipHostMallocDefault));
+    if (!ch.h_total) HIP_TRY(c, hipHostMalloc((void **)&ch.h_total, 2 * sizeof(uint64_t), hipHostMallocDefault));
+    if (!ch.h_status) HIP_TRY(c, hipHostMalloc((void **)&ch.h_status, 2 * sizeof(DevStatus), hipHostMallocDefault));
+    for (hipEvent_t &e : ch.ev)
+        if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(c, hipMemset(ch.d_params, 0, sizeof(ChainParams)));
-    memset(ch.h_params, 0, sizeof(ChainParams));
-    *ch.h_total = 0;
+    memset(ch.h_params, 0, 2 * sizeof(ChainParams));
+    memset(ch.h_status, 0, 2 * sizeof(DevStatus));
+    ch.h_total[0] = ch.h_total[1] = 0;
     ch.mail = static_cast<ChainMail *>(mail_dev);
     ch.gather = static_cast<uint8_t *>(gather_dev);
     ch.gather_cap = gather_cap;
     ch.rank = rank; ch.world = world;
     ch.pass = 0;
-    ch.pending = false;
+    ch.taken = 0;
     // how long a gate waits for another rank before the pass fails (wall clock of the device, 100 MHz)
     long ms = 10000;
     if (const char *ev = getenv("JPG_CHAIN_TIMEOUT_MS")) ms = atol(ev) > 0 ? atol(ev) : ms;
@@ -1057,14 +1057,19 @@ extern "C" int jpg_chain_pass_async(jpg_ctx *c, uint64_t active_mask) {
     if (!c) return JPG_ERR_BAD_ARG;
     jpg_ctx::Chain &ch = c->chain;
     if (!ch.mail) return JPG_ERR_STATE;
-    if (c->stage < ST_COEF || ch.pending || !code_from_rows(c)) return JPG_ERR_STATE;   // a loaded stripe the coding kernel takes
+    if (c->stage < ST_COEF || !code_from_rows(c)) return JPG_ERR_STATE;   // a loaded stripe the coding kernel takes
+    if (ch.pass - ch.taken >= 2) return JPG_ERR_STATE;                    // two passes are queued already: take one first
     if (!((active_mask >> ch.rank) & 1)) return JPG_ERR_BAD_ARG;
     if (ch.world < 64 && (active_mask >> ch.world)) return JPG_ERR_BAD_ARG;
     DeviceGuard dg;
     if (int e = use_device(c, dg)) return e;
     c->npend = 0;
-    if (int e = prepare_slot(c, true)) return e;
+    const int par = (int)(ch.pass & 1);
+    S(c).h_status_alt = &ch.h_status[par];
+    if (int e = prepare_slot(c, true)) { S(c).h_status_alt = nullptr; return e; }
     jpg_ctx::Slot &sl = S(c);
+    ch.epoch_of[par] = sl.eb.epoch;
+    ch.nchunks_of[par] = sl.eb.nchunks;
     int pred_rank = -1, last_rank = ch.rank;
     for (int k = 0; k < ch.world; k++) {
         if (!((active_mask >> k) & 1)) continue;
@@ -1075,8 +1080,7 @@ extern "C" int jpg_chain_pass_async(jpg_ctx *c, uint64_t active_mask) {
     const ChainPass cp{ch.mail, ch.d_params, sl.eb.status, sl.eb.epoch, 0x8000u | (uint32_t)(pass & 0x7fff), (int)(pass & 1),
                        ch.rank, pred_rank, active_mask, ch.timeout_ticks};
     // the stripe's last DC coefficients (straight from its last MCU's pixels), published; the predecessor's fetched
-    HIP_TRY(c, launch_last_dc_pixels(c->g, c->algo, c->d_src, c->d_dc, c->stream));
-    HIP_TRY(c, launch_chain_pred(cp, c->d_dc, c->stream));
+    HIP_TRY(c, launch_last_dc_pixels(c->g, c->algo, c->d_src, c->d_dc, c->stream, &cp));
     sl.eb.chain = ch.d_params;
     sl.eb.chain_slot = ch.mail + cp.parity * CHAIN_MAX_RANKS + ch.rank;
     sl.eb.chain_tag = cp.tag;
@@ -1091,13 +1095,15 @@ extern "C" int jpg_chain_pass_async(jpg_ctx *c, uint64_t active_mask) {
     }
     if (!e && he == hipSuccess) e = queue_stuff(c, 0, 0, ch.rank == last_rank, c->stream);   // shift and head bits from the gate
     sl.eb.chain = nullptr; sl.eb.chain_slot = nullptr; sl.eb.chain_tag = 0;
+    sl.h_status_alt = nullptr;
+    // (a pass that could not be queued whole still counts: the ranks number their passes alike, and its gates run dry)
+    if (!e && he == hipSuccess) he = launch_chain_offset(cp, ch.gather_cap, c->stream);
+    if (!e && he == hipSuccess) he = launch_chain_copy(cp, sl.eb.scan, ch.gather, c->stream);
+    if (!e && he == hipSuccess) he = launch_chain_done(cp, ch.rank == 0 ? &ch.h_total[par] : nullptr, c->stream);
+    if (!e && he == hipSuccess) he = hipMemcpyAsync(&ch.h_params[par], ch.d_params, sizeof(ChainParams), hipMemcpyDeviceToHost, c->stream);
+    (void)hipEventRecord(ch.ev[par], c->stream);
     if (e) return e;
     HIP_TRY(c, he);
-    HIP_TRY(c, launch_chain_offset(cp, ch.gather_cap, c->stream));
-    HIP_TRY(c, launch_chain_copy(cp, sl.eb.scan, ch.gather, c->stream));
-    HIP_TRY(c, launch_chain_done(cp, ch.rank == 0 ? ch.h_total : nullptr, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(ch.h_params, ch.d_params, sizeof(ChainParams), hipMemcpyDeviceToHost, c->stream));
-    ch.pending = true;
     return JPG_OK;
 }
 
@@ -1105,24 +1111,30 @@ extern "C" int jpg_chain_pass_finish(jpg_ctx *c, uint64_t *nbits, size_t *piece_
                                      size_t *total) {
     if (!c) return JPG_ERR_BAD_ARG;
     jpg_ctx::Chain &ch = c->chain;
-    if (!ch.pending) return JPG_ERR_STATE;
+    if (ch.pass == ch.taken) return JPG_ERR_STATE;
     DeviceGuard dg;
     if (int e = use_device(c, dg)) return e;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    ch.pending = false;
+    const int par = (int)(ch.taken & 1);                         // the oldest pass not handed out yet
+    HIP_TRY(c, hipEventSynchronize(ch.ev[par]));
+    ch.taken++;
     jpg_ctx::Slot &sl = S(c);
-    if (int ke = kernel_error(sl)) return ke;
-    sl.nbits = sl.h_status->nbits;
-    sl.scan_len = (size_t)sl.h_status->scan_bytes;
-    note_tile_bits(c, sl);
+    const DevStatus &hs = ch.h_status[par];
+    {
+        const int v = -hs.error;
+        if (v > 0 && (uint32_t)(v >> 8) == ch.epoch_of[par]) return -(v & 0xff);
+    }
+    sl.nbits = hs.nbits;
+    sl.scan_len = (size_t)hs.scan_bytes;
+    if (ch.nchunks_of[par] > 0) c->tile_bits = (double)hs.nbits / (double)ch.nchunks_of[par];
     c->stage = ST_SCAN;
-    if (ch.h_params->failed) return JPG_ERR_CHAIN;
-    if (ch.rank == 0 && (*ch.h_total >> 63)) return JPG_ERR_CHAIN;
+    const ChainParams &hp = ch.h_params[par];
+    if (hp.failed) return JPG_ERR_CHAIN;
+    if (ch.rank == 0 && (ch.h_total[par] >> 63)) return JPG_ERR_CHAIN;
     if (nbits) *nbits = sl.nbits;
     if (piece_len) *piece_len = sl.scan_len;
-    if (bit_offset) *bit_offset = ch.h_params->bit_offset;
-    if (byte_offset) *byte_offset = (size_t)ch.h_params->byte_offset;
-    if (total) *total = ch.rank == 0 ? (size_t)(*ch.h_total & ~(1ull << 63)) : 0;
+    if (bit_offset) *bit_offset = hp.bit_offset;
+    if (byte_offset) *byte_offset = (size_t)hp.byte_offset;
+    if (total) *total = ch.rank == 0 ? (size_t)(ch.h_total[par] & ~(1ull << 63)) : 0;
     return JPG_OK;
 }
 

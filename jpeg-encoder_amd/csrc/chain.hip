@@ -8,71 +8,11 @@
 // the kernel that needs it: a gate is one wave that polls, leaves the values in the context's ChainParams and ends,
 // so the heavy kernels never wait themselves and a waiting rank holds one wave slot, not a grid.  Every wait is
 // bounded (wall clock) and ends in an error, never in a hang.
-#include "../../include/jpeg_hip.h"
-
-#include "internal.hpp"
+#include "chain.hpp"
 
 namespace jpg {
 
 namespace {
-
-constexpr uint64_t VALUE_MASK = (1ull << 48) - 1;
-constexpr uint64_t DONE_ERROR = 1ull << 47;
-
-__device__ __forceinline__ uint64_t mail_pack(uint32_t tag, uint64_t value) { return ((uint64_t)tag << 48) | (value & VALUE_MASK); }
-
-// the mailbox lies in host memory shared by several GPUs (and processes): system scope
-__device__ __forceinline__ void mail_store(uint64_t *p, uint64_t w) {
-    __hip_atomic_store(p, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ uint64_t mail_load(const uint64_t *p) {
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// Poll *p until it carries `tag` (lanes with need == false do not poll); all lanes of the wave leave together.
-// Returns the value, or 0 with `timeout` set when the clock ran out.
-__device__ __forceinline__ uint64_t mail_wait(const uint64_t *p, bool need, uint32_t tag, uint64_t timeout_ticks, bool &timeout) {
-    uint64_t w = 0;
-    bool ok = !need;
-    const uint64_t t0 = wall_clock64();
-    for (uint32_t spin = 0;; spin++) {
-        if (!ok) {
-            w = mail_load(p);
-            ok = (w >> 48) == tag;
-        }
-        if (__ballot(!ok) == 0) break;
-        if ((spin & 15) == 15 && wall_clock64() - t0 > timeout_ticks) { timeout = true; break; }
-        __builtin_amdgcn_s_sleep(8);
-    }
-    return need && ok ? (w & VALUE_MASK) : 0;
-}
-
-__device__ __forceinline__ void chain_fail(const ChainPass &c) {
-    c.params->failed = 1;
-    atomicMin(&c.status->error, -(int)((c.err_epoch << 8) | (uint32_t)(-JPG_ERR_CHAIN)));
-}
-
-__global__ __launch_bounds__(64) void k_chain_pred(ChainPass c, const int16_t *dc3) {
-    const int lane = threadIdx.x;
-    ChainMail *box = c.mail + c.parity * CHAIN_MAX_RANKS;
-    if (lane == 0) {
-        c.params->failed = 0;
-        if (dc3) {
-            const uint64_t v = ((uint64_t)(uint16_t)dc3[0] << 32) | ((uint64_t)(uint16_t)dc3[1] << 16) | (uint16_t)dc3[2];
-            mail_store(&box[c.rank].dc, mail_pack(c.tag, v));
-        }
-    }
-    bool timeout = false;
-    const bool need = lane == 0 && c.pred_rank >= 0;
-    const uint64_t v = mail_wait(&box[need ? c.pred_rank : 0].dc, need, c.tag, c.timeout_ticks, timeout);
-    if (lane == 0) {
-        c.params->pred[0] = (int16_t)(v >> 32);       // src/jpeg/entropy_coding.rs:38-40: zero without a predecessor
-        c.params->pred[1] = (int16_t)(v >> 16);
-        c.params->pred[2] = (int16_t)v;
-        c.params->pred[3] = 0;
-    }
-    if (__ballot(timeout) && lane == 0) chain_fail(c);
-}
 
 // lane k looks after rank k
 __global__ __launch_bounds__(64) void k_chain_place(ChainPass c) {
@@ -124,8 +64,15 @@ __global__ __launch_bounds__(64) void k_chain_offset(ChainPass c, unsigned long 
     }
 }
 
-// dst may have any alignment (it follows the pieces before it): 16-byte stores on its aligned part, each put together
-// from the source dwords around it; single bytes at both ends.
+// dst may have any alignment (it follows the pieces before it): 16 bytes per thread and round on its aligned part, each
+// put together from the source dwords around them; single bytes at both ends.  The stores are system-scope
+// (write-through: the destination may be another GPU's memory or host memory), so that the piece is in place when the
+// kernel has ended and the next kernel in the stream says so; no fence inside the kernel (a system-scope fence writes
+// the whole L2 back, once per wave).
+__device__ __forceinline__ void store_through(uint64_t *p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(256) void k_chain_copy(const ChainParams *params, const uint8_t *__restrict__ src,
                                                      uint8_t *__restrict__ gather) {
     const uint64_t len = params->len;
@@ -135,26 +82,26 @@ __global__ __launch_bounds__(256) void k_chain_copy(const ChainParams *params, c
     const uint64_t body = (len - head) / 16;                     // 16-byte pieces
     const uint64_t tail0 = head + body * 16;
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (uint64_t)gridDim.x * blockDim.x;
-    if (t < head) dst[t] = src[t];
-    if (t < len - tail0) dst[tail0 + t] = src[tail0 + t];
-    // source of piece i starts at src + head + 16 i: dword index and byte phase (src itself is 16-byte aligned)
-    const uint32_t *sw = reinterpret_cast<const uint32_t *>(src);
-    const uint32_t phase = (uint32_t)(head & 3) * 8;
-    const uint64_t w0 = head >> 2;
-    uint4 *dv = reinterpret_cast<uint4 *>(dst + head);
+    if (t < head) __hip_atomic_store(&dst[t], src[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t < len - tail0) __hip_atomic_store(&dst[tail0 + t], src[tail0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // source of piece i starts at src + head + 16 i: inside two consecutive aligned 16-byte pieces of src (src itself
+    // is 16-byte aligned), `sh` bytes into the first
+    const uint4 *sv = reinterpret_cast<const uint4 *>(src);
+    const uint32_t sh = (uint32_t)(head & 15);
+    const uint32_t dw = sh >> 2, phase = (sh & 3) * 8;
+    uint64_t *dv = reinterpret_cast<uint64_t *>(dst + head);
     for (uint64_t i = t; i < body; i += nt) {
-        const uint64_t w = w0 + 4 * i;
+        const uint4 A = sv[i], B = sv[i + 1];                    // (the buffer is padded beyond len: B stays inside)
+        const uint32_t w[8] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
         uint32_t a[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++) a[k] = sw[w + k];          // (the buffer is padded beyond len: the fifth read stays inside)
-        uint4 o;
-        o.x = phase ? __builtin_amdgcn_alignbit(a[1], a[0], phase) : a[0];
-        o.y = phase ? __builtin_amdgcn_alignbit(a[2], a[1], phase) : a[1];
-        o.z = phase ? __builtin_amdgcn_alignbit(a[3], a[2], phase) : a[2];
-        o.w = phase ? __builtin_amdgcn_alignbit(a[4], a[3], phase) : a[3];
-        dv[i] = o;
+        for (int k = 0; k < 5; k++) a[k] = dw == 0 ? w[k] : (dw == 1 ? w[k + 1] : (dw == 2 ? w[k + 2] : w[k + 3]));
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = phase ? __builtin_amdgcn_alignbit(a[k + 1], a[k], phase) : a[k];
+        store_through(&dv[2 * i], ((uint64_t)o[1] << 32) | o[0]);
+        store_through(&dv[2 * i + 1], ((uint64_t)o[3] << 32) | o[2]);
     }
-    __threadfence_system();
 }
 
 __global__ __launch_bounds__(64) void k_chain_done(ChainPass c, uint64_t *host_total) {
@@ -162,7 +109,6 @@ __global__ __launch_bounds__(64) void k_chain_done(ChainPass c, uint64_t *host_t
     const int lane = threadIdx.x;
     ChainMail *box = c.mail + c.parity * CHAIN_MAX_RANKS;
     if (lane == 0) {
-        __threadfence_system();
         mail_store(&box[c.rank].done, mail_pack(c.tag, (c.params->failed ? DONE_ERROR : 0) | c.params->len));
     }
     if (c.rank != 0) return;
@@ -193,12 +139,6 @@ bool pass_ok(const ChainPass &c) {
 }
 
 }  // namespace
-
-hipError_t launch_chain_pred(const ChainPass &c, const int16_t *dc3, hipStream_t s) {
-    if (!pass_ok(c)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_chain_pred, dim3(1), dim3(64), 0, s, c, dc3);
-    return hipGetLastError();
-}
 
 hipError_t launch_chain_place(const ChainPass &c, hipStream_t s) {
     if (!pass_ok(c)) return hipErrorInvalidValue;

@@ -21,6 +21,7 @@
 // tile to transform), so that no workgroup depends on another.
 #include <hip/hip_ext.h>
 
+#include "chain.hpp"
 #include "coding.hpp"
 #include "tile.hpp"
 
@@ -305,9 +306,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
 // The DC coefficients of the last Y, Cb, Cr blocks of MCU (mx, my), straight from the pixels: what a
 // following stripe starts its predictors from (src/jpeg/entropy_coding.rs:149-150).  One wave.
+// chain.mail != null: the first kernel of a pass of the stripe chain; the wave also publishes the three values for the
+// stripe after this one and waits for those of the stripe before it (chain_exchange_dc).
 template <int HS, int VS, int ALGO>
 __global__ __launch_bounds__(64) void k_mcu_dc(const uint8_t *__restrict__ src, Geom g, int mx, int my,
-                                               int16_t *__restrict__ dc3) {
+                                               int16_t *__restrict__ dc3, ChainPass chain) {
     using C = TileCfg<HS, VS>;
     __shared__ __attribute__((aligned(16))) uint8_t sHalo[C::HALO_BYTES];
     __shared__ int16_t sDc[4];
@@ -320,25 +323,27 @@ __global__ __launch_bounds__(64) void k_mcu_dc(const uint8_t *__restrict__ src, 
     else halo_dc<HS, VS, ALGO>(sHalo, sHalo + C::HALO_Y, sHalo + C::HALO_Y + 64, lane, sDc);
     __builtin_amdgcn_wave_barrier();
     if (lane < 3) dc3[lane] = sDc[lane];
+    if (chain.mail) chain_exchange_dc(chain, sDc, lane);
 }
 
 template <int HS, int VS>
-static hipError_t launch_mcu_dc_hv(const Geom &g, int algo, const uint8_t *src, int16_t *dc3, hipStream_t s) {
+static hipError_t launch_mcu_dc_hv(const Geom &g, int algo, const uint8_t *src, int16_t *dc3, const ChainPass &cp, hipStream_t s) {
     const int mx = g.mcux - 1, my = g.mcuy - 1;
     switch (algo) {
-        case ALGO_REAL: hipLaunchKernelGGL((k_mcu_dc<HS, VS, ALGO_REAL>), dim3(1), dim3(64), 0, s, src, g, mx, my, dc3); break;
-        case ALGO_BIN: hipLaunchKernelGGL((k_mcu_dc<HS, VS, ALGO_BIN>), dim3(1), dim3(64), 0, s, src, g, mx, my, dc3); break;
-        case ALGO_REAL_STRICT: hipLaunchKernelGGL((k_mcu_dc<HS, VS, ALGO_REAL_STRICT>), dim3(1), dim3(64), 0, s, src, g, mx, my, dc3); break;
+        case ALGO_REAL: hipLaunchKernelGGL((k_mcu_dc<HS, VS, ALGO_REAL>), dim3(1), dim3(64), 0, s, src, g, mx, my, dc3, cp); break;
+        case ALGO_BIN: hipLaunchKernelGGL((k_mcu_dc<HS, VS, ALGO_BIN>), dim3(1), dim3(64), 0, s, src, g, mx, my, dc3, cp); break;
+        case ALGO_REAL_STRICT: hipLaunchKernelGGL((k_mcu_dc<HS, VS, ALGO_REAL_STRICT>), dim3(1), dim3(64), 0, s, src, g, mx, my, dc3, cp); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_last_dc_pixels(const Geom &g, int algo, const uint8_t *src, int16_t *dc3, hipStream_t s) {
+hipError_t launch_last_dc_pixels(const Geom &g, int algo, const uint8_t *src, int16_t *dc3, hipStream_t s, const ChainPass *chain) {
     if ((reinterpret_cast<uintptr_t>(src) & 3) || (g.stride & 3)) return hipErrorInvalidValue;
-    if (g.h == 2 && g.v == 2) return launch_mcu_dc_hv<2, 2>(g, algo, src, dc3, s);
-    if (g.h == 2 && g.v == 1) return launch_mcu_dc_hv<2, 1>(g, algo, src, dc3, s);
-    if (g.h == 1 && g.v == 1) return launch_mcu_dc_hv<1, 1>(g, algo, src, dc3, s);
+    const ChainPass cp = chain ? *chain : ChainPass{};
+    if (g.h == 2 && g.v == 2) return launch_mcu_dc_hv<2, 2>(g, algo, src, dc3, cp, s);
+    if (g.h == 2 && g.v == 1) return launch_mcu_dc_hv<2, 1>(g, algo, src, dc3, cp, s);
+    if (g.h == 1 && g.v == 1) return launch_mcu_dc_hv<1, 1>(g, algo, src, dc3, cp, s);
     return hipErrorInvalidValue;
 }
 

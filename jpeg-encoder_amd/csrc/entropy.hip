@@ -689,18 +689,27 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 // assembled.  One workgroup: a 64-bit sum of the chunk lengths, then one thread walks back from the last
 // chunk until it has 32 bits.
 // chain_slot: where a stripe of a chain publishes both for the stripes after it (host memory shared by the GPUs).
-__global__ __launch_bounds__(256) void k_tail(const uint32_t *__restrict__ sparse, const uint32_t *__restrict__ clen,
-                                              long long nchunks, size_t slot_words, DevStatus *status, DevStatus *host_status,
-                                              ChainMail *chain_slot, uint32_t chain_tag) {
-    __shared__ uint64_t sSum[4];
+__global__ __launch_bounds__(1024) void k_tail(const uint32_t *__restrict__ sparse, const uint32_t *__restrict__ clen,
+                                               long long nchunks, size_t slot_words, DevStatus *status, DevStatus *host_status,
+                                               ChainMail *chain_slot, uint32_t chain_tag) {
+    __shared__ uint64_t sSum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the lengths, 16 bytes per load (the array is padded to a multiple of 64 words; clen is 16-byte aligned)
     uint64_t sum = 0;
-    for (long long c = tid; c < nchunks; c += 256) sum += clen[c];
+    const long long quads = nchunks >> 2;
+    const uint4 *q = reinterpret_cast<const uint4 *>(clen);
+    for (long long i = tid; i < quads; i += 1024) {
+        const uint4 v = q[i];
+        sum += (uint64_t)v.x + v.y + v.z + v.w;
+    }
+    if (tid < (int)(nchunks & 3)) sum += clen[(quads << 2) + tid];
     sum = wave_sum64(sum);
     if (lane == 0) sSum[wave] = sum;
     __syncthreads();
     if (tid != 0) return;
-    const uint64_t nbits = sSum[0] + sSum[1] + sSum[2] + sSum[3];
+    uint64_t nbits = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) nbits += sSum[w];
     uint32_t acc = 0, got = 0;
     for (long long c = nchunks - 1; c >= 0 && got < 32; c--) {
         const uint32_t L = clen[c];
@@ -724,7 +733,7 @@ __global__ __launch_bounds__(256) void k_tail(const uint32_t *__restrict__ spars
 
 hipError_t launch_tail(const EntropyBufs &b, hipStream_t s) {
     if ((b.nimg > 0 ? b.nimg : 1) != 1 || b.slot_words <= 0) return hipErrorInvalidValue;   // single images only
-    hipLaunchKernelGGL(k_tail, dim3(1), dim3(256), 0, s, b.sparse, b.clen, b.nchunks, (size_t)b.slot_words, b.status,
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), 0, s, b.sparse, b.clen, b.nchunks, (size_t)b.slot_words, b.status,
                        b.host_status, b.chain_slot, b.chain_tag);
     return hipGetLastError();
 }

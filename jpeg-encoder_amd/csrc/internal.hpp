@@ -134,9 +134,8 @@ struct ChainPass {
     uint64_t active;            // bit k: rank k has a stripe
     uint64_t timeout_ticks;     // of the 100 MHz clock: how long a gate waits for another rank
 };
-// first kernel of a pass: clears params->failed, publishes dc3[0..2] (device memory: the DC coefficients of this
-// stripe's last blocks), then waits for the predecessor's -> params->pred
-hipError_t launch_chain_pred(const ChainPass &c, const int16_t *dc3, hipStream_t s);
+// (the first kernel of a pass is launch_last_dc_pixels with the pass: it clears params->failed, publishes the DC
+// coefficients of the stripe's last blocks and waits for the predecessor's -> params->pred)
 // gate: wait for bit count and last bits of every earlier stripe -> params->shift / head / bit_offset
 hipError_t launch_chain_place(const ChainPass &c, hipStream_t s);
 // publishes the piece's length (status->scan_bytes), waits for the earlier pieces' -> params->byte_offset / len
@@ -180,7 +179,10 @@ hipError_t launch_coded(const Geom &g, int algo, const uint8_t *src, const uint8
                         const int16_t pred[3], const EntropyBufs &b, hipStream_t s, hipEvent_t e0 = nullptr,
                         hipEvent_t e1 = nullptr, int mcu_row0 = 0, int mcu_rows = -1);
 // the DC coefficients of the last Y, Cb, Cr blocks of the image, computed from its pixels
-hipError_t launch_last_dc_pixels(const Geom &g, int algo, const uint8_t *src, int16_t *dc3, hipStream_t s);
+// chain: the launch is the first kernel of a pass of the stripe chain: the values are also published for the stripe
+// after this one and those of the stripe before it are waited for and left in chain->params->pred
+hipError_t launch_last_dc_pixels(const Geom &g, int algo, const uint8_t *src, int16_t *dc3, hipStream_t s,
+                                 const ChainPass *chain = nullptr);
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s);
 // writes the dense stream to b.bits
 hipError_t launch_dense(const EntropyBufs &b, hipStream_t s);

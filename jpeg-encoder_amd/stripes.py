@@ -132,6 +132,14 @@ class ScalarExchange:
         self.dist.barrier(group=self.group)
 
 
+def _unlink_quietly(path):
+    import os
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
+
+
 class ShmExchange:
     """The same exchange through a small file in shared host memory (/dev/shm): every rank owns a record of a
     sequence number and up to WORDS int64 and publishes by writing the values, then the number; readers spin on
@@ -159,6 +167,9 @@ class ShmExchange:
                 time.sleep(0.001)
         self.mem = np.memmap(self.path, np.int64, "r+", shape=(world, 2, 1 + self.WORDS))
         self.seq = 0
+        if rank == 0:                                      # the file goes away with the process even when close() is never reached
+            import atexit
+            atexit.register(_unlink_quietly, self.path)
 
     @classmethod
     def from_group(cls, group=None):
@@ -195,14 +206,12 @@ class ShmExchange:
         self.all_gather([])
 
     def close(self):
-        import os
-        self.barrier()
-        del self.mem
-        if self.rank == 0:
-            try:
-                os.unlink(self.path)
-            except OSError:
-                pass
+        try:
+            self.barrier()
+        finally:
+            self.mem = None
+            if self.rank == 0:
+                _unlink_quietly(self.path)
 
 
 class DeviceGather:
@@ -216,13 +225,14 @@ class DeviceGather:
         self.own, self.own_cap = None, 0          # rank 0: the buffer
         self.words = None                         # ... and its exported handle as 8 int64
         self.opened = {}                          # other ranks: handle bytes -> device address in this process
+        self.retired = []                         # rank 0: outgrown buffers the other ranks may still have mapped
 
     def handle_words(self, cap):
         """Rank 0: (re)allocate for cap bytes and return the handle as 8 int64; others pass zeros."""
         import ctypes as C
         if cap > self.own_cap:
             if self.own:
-                self.L.jpg_device_free(self.device, self.own)
+                self.retired.append(self.own)             # still mapped by the other ranks: freed by release_retired()
             cap = max(cap, 1 << 20)
             self.own = self.L.jpg_device_alloc(self.device, cap)
             if not self.own:
@@ -242,11 +252,23 @@ class DeviceGather:
             return self.own
         raw = np.array(words, np.int64).tobytes()
         if raw not in self.opened:
+            # a new handle means rank 0 has outgrown the buffer this process had mapped: that mapping is closed
+            # before the barrier that lets rank 0 free the old allocation (encode_striped)
+            for p in self.opened.values():
+                self.L.jpg_ipc_close(p)
+            self.opened = {}
             h = (C.c_uint8 * self.N.IPC_HANDLE_BYTES).from_buffer_copy(raw)
             p = C.c_void_p()
             self.N.check(None, self.L.jpg_ipc_open(self.device, h, C.byref(p)))
             self.opened[raw] = p.value
         return self.opened[raw]
+
+    def release_retired(self):
+        """Rank 0, after a barrier behind the exchange that announced the new handle (every rank has closed its
+        mapping of the old buffers by then)."""
+        for p in self.retired:
+            self.L.jpg_device_free(self.device, p)
+        self.retired = []
 
     def read(self, n):
         out = np.zeros(n, np.uint8)
@@ -258,9 +280,126 @@ class DeviceGather:
         for p in self.opened.values():
             self.L.jpg_ipc_close(p)
         self.opened = {}
+        self.release_retired()
         if self.own:
             self.L.jpg_device_free(self.device, self.own)
             self.own, self.own_cap = None, 0
+
+
+class StripeChain:
+    """One process per GPU: the set-up of the stripe chain (jpg_chain_* in include/jpeg_hip.h), in which the ranks'
+    kernels hand each other the scalars of a pass through a mailbox in host memory and put the stuffed pieces at
+    their byte offsets in one gather buffer, so that a pass is queued at once and waited for once.
+
+    mailbox: page-locked host memory of rank 0, which the other ranks open through an inter-process handle and
+    their GPUs read and write directly (host memory is not cached by any GPU).
+    gather buffer: device memory of rank 0, opened by the other ranks the same way (`gather="device"`: the pieces
+    travel GPU to GPU); where that is not possible -- the open fails on some rank -- every rank falls back to
+    page-locked host memory of rank 0 (`gather="host"`: the pieces travel over PCIe), and `self.gather` says which.
+    `exchange` (ScalarExchange or ShmExchange) is only used here, to pass the handles around.  Kept across passes;
+    close() on every rank."""
+
+    def __init__(self, encoder, exchange, gather_cap, gather="auto"):
+        from . import _native as N
+        self.N, self.L, self.enc, self.ex = N, N.lib(), encoder, exchange
+        self.rank, self.world, self.device = exchange.rank, exchange.world, encoder.device
+        self.cap = max(int(gather_cap), 1)
+        self._mine = []                   # rank 0: (address, free function) of what it allocated
+        self._opened = []                 # other ranks: addresses opened through handles
+        self.mailbox = self._share(self.L.jpg_chain_mailbox_alloc, self.L.jpg_free, required=True)
+        self.gather, self.buffer = None, None
+        if gather in ("auto", "device"):
+            self.buffer = self._share(lambda: self.L.jpg_device_alloc(self.device, self.cap),
+                                      lambda p: self.L.jpg_device_free(self.device, p), required=gather == "device")
+            if self.buffer:
+                self.gather = "device"
+        if not self.buffer:
+            self.buffer = self._share(lambda: self.L.jpg_host_alloc(self.cap), self.L.jpg_free, required=True)
+            self.gather = "host"
+        encoder.chain_setup(self.rank, self.world, self.mailbox, self.buffer, self.cap)
+        exchange.barrier()                # every rank is set up before any rank's kernels use the mailbox
+
+    def _share(self, alloc, free, required):
+        """Rank 0 allocates and exports, the others open: the address in this process, or None when some rank could
+        not get at it (every rank then lets go of it again)."""
+        import ctypes as C
+        N = self.N
+        ok, words, mine = 1, [0] * 8, None
+        if self.rank == 0:
+            mine = alloc()
+            h = (C.c_uint8 * N.IPC_HANDLE_BYTES)()
+            ok = int(bool(mine) and self.L.jpg_ipc_export(mine, h) == 0)
+            words = [int(x) for x in np.frombuffer(bytes(h), np.int64)]
+        got = self.ex.all_gather([ok] + words)
+        ok, addr = got[0][0], mine
+        if ok and self.rank != 0:
+            h = (C.c_uint8 * N.IPC_HANDLE_BYTES).from_buffer_copy(np.array(got[0][1:], np.int64).tobytes())
+            p = C.c_void_p()
+            ok = int(self.L.jpg_ipc_open(self.device, h, C.byref(p)) == 0 and bool(p.value))
+            addr = p.value if ok else None
+        everyone = min(g[0] for g in self.ex.all_gather([ok]))
+        if everyone:
+            if self.rank == 0:
+                self._mine.append((mine, free))
+            else:
+                self._opened.append(addr)
+            return addr
+        if self.rank != 0 and addr:
+            self.L.jpg_ipc_close(addr)
+        self.ex.barrier()                 # no rank has it mapped any more
+        if mine:
+            free(mine)
+        if required:
+            raise RuntimeError("memory of rank 0 cannot be opened on every rank through an inter-process handle")
+        return None
+
+    def encode_async(self, width, height, stride, v, stripe_ptr=None, rows=None, bottom_up=True):
+        """Queues one pass: this rank's stripe (device rows at stripe_ptr, or sliced out of the host array `rows` of the
+        whole image) through the chain.  Up to two passes may be queued before finish() takes the first.  True when
+        this rank has a stripe (only then is there something to finish)."""
+        plan = plan_stripes(height, v, self.world)
+        mask = sum(1 << k for k, (a, b) in enumerate(plan) if b > a)
+        y0, y1 = plan[self.rank]
+        if y1 <= y0:
+            return False
+        if stripe_ptr is not None:
+            self.enc.stripe_device(stripe_ptr, width, y1 - y0, stride, bottom_up)
+        else:
+            self.enc.front_host(stripe_rows(rows, height, y0, y1, bottom_up), width, y1 - y0, stride, bottom_up)
+        self.enc.chain_pass_async(mask)
+        return True
+
+    def finish(self):
+        """Waits for the oldest queued pass.  The length of the whole scan on rank 0 -- whose pass ends when every
+        piece lies in the gather buffer -- and None elsewhere."""
+        total = self.enc.chain_pass_finish()[4]
+        return total if self.rank == 0 else None
+
+    def encode(self, width, height, stride, v, stripe_ptr=None, rows=None, bottom_up=True):
+        """One pass, queued and waited for."""
+        if not self.encode_async(width, height, stride, v, stripe_ptr, rows, bottom_up):
+            return None
+        return self.finish()
+
+    def read(self, n):
+        """Rank 0: the first n bytes of the gather buffer."""
+        import ctypes as C
+        out = np.zeros(n, np.uint8)
+        if n and self.gather == "device":
+            self.N.check(None, self.L.jpg_device_to_host(self.device, out.ctypes.data, self.buffer, n))
+        elif n:
+            C.memmove(out.ctypes.data, self.buffer, n)
+        return out
+
+    def close(self):
+        self.enc.sync()
+        for p in self._opened:
+            self.L.jpg_ipc_close(p)
+        self._opened = []
+        self.ex.barrier()                 # no rank has rank 0's memory mapped any more
+        for p, free in self._mine:
+            free(p)
+        self._mine = []
 
 
 def encode_striped(backend, rows, width, height, stride, v, bottom_up=True, group=None, device=None, exchange=None,
@@ -291,6 +430,7 @@ def encode_striped(backend, rows, width, height, stride, v, bottom_up=True, grou
             backend.scan_copy_to_device(base + sum(lens[:rank]), -1, n)
         backend.sync()
         ex.barrier()                                             # every piece has landed
+        gather.release_retired()                                 # (and every rank has let go of an outgrown buffer)
         if rank != 0:
             return None
         return gather.read(sum(lens)) if fetch else sum(lens)

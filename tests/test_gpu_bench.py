@@ -32,12 +32,26 @@ def test_gpus_2_starts_two_ranks_batch():
     assert out["value"] > 0
 
 
-def test_gpus_3_stripes_equal_the_whole_image():
+@pytest.mark.parametrize("extra,protocol,gather", [((), "chain", "device"), (("--gather", "host"), "chain", "host"),
+                                                   (("--stripe-protocol", "host"), "host", "device")])
+def test_gpus_3_stripes_equal_the_whole_image(extra, protocol, gather):
+    """Three processes, one stripe each: the stripe chain (the ranks' kernels hand the scalars on through a mailbox of
+    rank 0 opened by the others; the pieces meet in rank 0's device memory, or in its page-locked host memory, the
+    fallback where GPUs cannot open each other's memory) and the earlier protocol with host exchanges between the
+    steps; the stitched scan is compared with the whole-image encode."""
     out, err = run_bench("--gpus", "3", "--config", "5", "--steps", "2", "--warmup", "1", "--width", "2048", "--height",
-                         "1008", "--passes", "2", "--no-cpu-baseline", "--verify")
+                         "1008", "--passes", "3", "--no-cpu-baseline", "--verify", *extra)
     assert out["n_gpus"] == 3 and out["scaling"] == "strong"
     assert out["config"]["stripes"] == 3
+    assert out["config"]["stripe_protocol"] == protocol and out["config"]["gather"] == gather
+    assert out["config"]["control_plane"] == "gloo"
     assert "verified" in err
+
+
+def test_gpus_5_stripes_with_ranks_that_have_no_rows():
+    out, err = run_bench("--gpus", "5", "--config", "5", "--steps", "1", "--warmup", "1", "--width", "1024", "--height",
+                         "40", "--passes", "2", "--no-cpu-baseline", "--verify")
+    assert out["config"]["stripes"] == 5 and "verified" in err
 
 
 def test_one_rank_line_has_the_roofs_and_figures():
