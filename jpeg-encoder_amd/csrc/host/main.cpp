@@ -216,6 +216,50 @@ std::vector<uint8_t> encode_striped(const Args &args, const jph_bmp &bmp, int v,
         if ((st = jpg_stripe_host_async(ctx[k], rows, bmp.width, y1[k] - y0[k], bmp.row_stride, 1)) != JPG_OK) fail_all(k, st);
         active.push_back(k);
     }
+    // The stripe chain where it applies (images at least one tile wide): a whole pass is queued on every context,
+    // lowest rank first, and the kernels hand the linking scalars on themselves through a mailbox in page-locked
+    // host memory; the pieces meet in a buffer on the first device when every device can write there, else in
+    // page-locked host memory.  Anything it refuses (JPG_ERR_STATE: narrow image; JPG_ERR_CHAIN: scan larger than
+    // the buffer) falls through to the steps below.
+    if (n <= 64 && !active.empty() && active[0] == 0) {
+        const size_t cap = (size_t)bmp.width * (size_t)bmp.height / 2 + (1u << 20);
+        void *mailbox = jpg_chain_mailbox_alloc();
+        bool peers = true;
+        for (int k : active) peers = peers && jpg_peer_access(args.devices[k % args.devices.size()], owner) == 1;
+        void *gather = peers ? jpg_device_alloc(owner, cap) : jpg_host_alloc(cap);
+        uint64_t mask = 0;
+        for (int k : active) mask |= 1ull << k;
+        bool ok = mailbox && gather;
+        for (size_t i = 0; ok && i < active.size(); i++) ok = jpg_chain_setup(ctx[active[i]], active[i], n, mailbox, gather, cap) == JPG_OK;
+        size_t queued = 0;
+        for (; ok && queued < active.size(); queued++) ok = jpg_chain_pass_async(ctx[active[queued]], mask) == JPG_OK;
+        size_t total = 0;
+        for (size_t i = queued; i-- > 0;) {   // everything queued is waited for, whatever happened
+            size_t t = 0;
+            const int st = jpg_chain_pass_finish(ctx[active[i]], nullptr, nullptr, nullptr, nullptr, &t);
+            if (st != JPG_OK) ok = false;
+            if (i == 0) total = t;
+        }
+        std::vector<uint8_t> scan;
+        if (ok) {
+            scan.resize(total);
+            if (total && peers) ok = jpg_device_to_host(owner, scan.data(), gather, total) == JPG_OK;
+            else if (total) std::memcpy(scan.data(), gather, total);
+        }
+        if (gather && peers) jpg_device_free(owner, gather);
+        else if (gather) jpg_free(gather);
+        if (mailbox) jpg_free(mailbox);
+        if (ok) {
+            for (int k = 0; k < n; k++)
+                if (ctx[k]) jpg_destroy(ctx[k]);
+            return scan;
+        }
+        // (the stripes are still loaded in their contexts: the steps below start from them)
+        for (int k : active)
+            if (int st = jpg_stripe_host_async(ctx[k], bmp.pixels + (size_t)(bmp.height - y1[k]) * bmp.row_stride, bmp.width,
+                                               y1[k] - y0[k], bmp.row_stride, 1))
+                fail_all(k, st);
+    }
     // the DC values the following stripe predicts from: the last MCU of each stripe, transformed on its own
     std::vector<int16_t> dc(3 * (size_t)n, 0);
     for (int k : active)
