@@ -266,12 +266,15 @@ int jpg_ipc_close(void *dev_ptr);
  *  - jpg_chain_pass_async: after jpg_stripe_device / jpg_stripe_host_async has named the stripe's rows (images
  *    at least one tile wide: JPG_ERR_STATE otherwise), queues the whole pass on the context's stream and
  *    returns.  active_mask: bit k set when rank k has a stripe (ranks without rows make no call).
- *    One process driving several contexts queues the ranks in ascending order (a gate only waits for lower ranks).
+ *    One process driving several contexts queues the ranks in ascending order, all of them before it waits for
+ *    any: a gate only waits for lower ranks, so nothing queued can wait for something behind it in a hardware queue.
  *    Two passes may be queued before the first is taken (the host queues one while the other runs); a third is
  *    refused with JPG_ERR_STATE.
  *  - jpg_chain_pass_finish waits for the context's oldest queued pass: the stripe's bit count, the length of its stuffed
- *    piece, where its bits and its piece start, and on rank 0 -- whose pass ends when every piece lies in the
- *    gather buffer -- the length of the whole scan (0 elsewhere).  Any of the pointers may be NULL. */
+ *    piece, where its bits and its piece start, and on rank 0 the length of the whole scan (0 elsewhere): the last
+ *    rank with a stripe publishes it in the mailbox when every piece lies in the gather buffer, and rank 0's call
+ *    waits for that word on the host -- rank 0 therefore passes a mailbox address its host can read (its own
+ *    allocation).  Any of the pointers may be NULL. */
 size_t jpg_chain_mailbox_bytes(void);
 void *jpg_chain_mailbox_alloc(void);
 /* 1 when kernels on `device` can write memory of `peer` (peer access is switched on by the call), else 0 */

@@ -2,10 +2,12 @@
 // management around the kernels of front.hip, staged.hip and entropy.hip.
 #include "../../include/jpeg_hip.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 
 #include "internal.hpp"
 
@@ -98,13 +100,14 @@ struct jpg_ctx {
     // hand-over record between its gate kernels and the kernels behind them, and the pass counter
     struct Chain {
         ChainMail *mail = nullptr;          // device-side address of the mailbox (host memory)
+        const ChainMail *mail_host = nullptr;   // the address the host reads it by (rank 0 only needs it)
         uint8_t *gather = nullptr; size_t gather_cap = 0;
         int rank = 0, world = 0;
         ChainParams *d_params = nullptr;    // device
         // Two passes may be queued before the first is taken: the page-locked records a pass reports through exist
         // twice, indexed by the parity of the pass number
         ChainParams *h_params = nullptr;    // [2] copies of d_params, made at the end of a pass
-        uint64_t *h_total = nullptr;        // [2] the collector's last kernel writes the whole scan's length here
+        int last_of[2] = {0, 0};            // the last rank with a stripe in the pass: it publishes the scan's length
         DevStatus *h_status = nullptr;      // [2] status records of the passes
         hipEvent_t ev[2] = {nullptr, nullptr};   // end of a pass
         uint32_t epoch_of[2] = {0, 0};      // epoch the pass's errors are tagged with
@@ -276,7 +279,6 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
     if (c->h_dc) (void)hipHostFree(c->h_dc);
     if (c->chain.d_params) (void)hipFree(c->chain.d_params);
     if (c->chain.h_params) (void)hipHostFree(c->chain.h_params);
-    if (c->chain.h_total) (void)hipHostFree(c->chain.h_total);
     if (c->chain.h_status) (void)hipHostFree(c->chain.h_status);
     for (hipEvent_t e : c->chain.ev)
         if (e) (void)hipEventDestroy(e);
@@ -1032,15 +1034,14 @@ extern "C" int jpg_chain_setup(jpg_ctx *c, int rank, int world, void *mailbox, v
     if (int e = device_address_of_host(c, gather, &gather_dev)) return e;
     if (!ch.d_params) HIP_TRY(c, hipMalloc((void **)&ch.d_params, sizeof(ChainParams)));
     if (!ch.h_params) HIP_TRY(c, hipHostMalloc((void **)&ch.h_params, 2 * sizeof(ChainParams), hipHostMallocDefault));
-    if (!ch.h_total) HIP_TRY(c, hipHostMalloc((void **)&ch.h_total, 2 * sizeof(uint64_t), hipHostMallocDefault));
     if (!ch.h_status) HIP_TRY(c, hipHostMalloc((void **)&ch.h_status, 2 * sizeof(DevStatus), hipHostMallocDefault));
     for (hipEvent_t &e : ch.ev)
         if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(c, hipMemset(ch.d_params, 0, sizeof(ChainParams)));
     memset(ch.h_params, 0, 2 * sizeof(ChainParams));
     memset(ch.h_status, 0, 2 * sizeof(DevStatus));
-    ch.h_total[0] = ch.h_total[1] = 0;
     ch.mail = static_cast<ChainMail *>(mail_dev);
+    ch.mail_host = static_cast<const ChainMail *>(mailbox);
     ch.gather = static_cast<uint8_t *>(gather_dev);
     ch.gather_cap = gather_cap;
     ch.rank = rank; ch.world = world;
@@ -1099,7 +1100,8 @@ extern "C" int jpg_chain_pass_async(jpg_ctx *c, uint64_t active_mask) {
     // (a pass that could not be queued whole still counts: the ranks number their passes alike, and its gates run dry)
     if (!e && he == hipSuccess) he = launch_chain_offset(cp, ch.gather_cap, c->stream);
     if (!e && he == hipSuccess) he = launch_chain_copy(cp, sl.eb.scan, ch.gather, c->stream);
-    if (!e && he == hipSuccess) he = launch_chain_done(cp, ch.rank == 0 ? &ch.h_total[par] : nullptr, c->stream);
+    ch.last_of[par] = last_rank;
+    if (!e && he == hipSuccess) he = launch_chain_done(cp, ch.rank == last_rank, c->stream);
     if (!e && he == hipSuccess) he = hipMemcpyAsync(&ch.h_params[par], ch.d_params, sizeof(ChainParams), hipMemcpyDeviceToHost, c->stream);
     (void)hipEventRecord(ch.ev[par], c->stream);
     if (e) return e;
@@ -1129,12 +1131,29 @@ extern "C" int jpg_chain_pass_finish(jpg_ctx *c, uint64_t *nbits, size_t *piece_
     c->stage = ST_SCAN;
     const ChainParams &hp = ch.h_params[par];
     if (hp.failed) return JPG_ERR_CHAIN;
-    if (ch.rank == 0 && (ch.h_total[par] >> 63)) return JPG_ERR_CHAIN;
+    // Rank 0 (the owner of the gather buffer) reports the whole scan: the last rank with a stripe publishes its length
+    // when every piece has landed; the host reads that word (the mailbox is host memory), for as long as a gate would wait.
+    uint64_t whole = 0;
+    if (ch.rank == 0) {
+        const uint64_t tag = 0x8000u | (uint32_t)((ch.taken - 1) & 0x7fff);
+        const uint64_t *word = &ch.mail_host[par * CHAIN_MAX_RANKS + ch.last_of[par]].total;
+        const auto t0 = std::chrono::steady_clock::now();
+        uint64_t w = 0;
+        for (;;) {
+            w = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+            if ((w >> 48) == tag) break;
+            const double ticks = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e8;
+            if (ticks > (double)ch.timeout_ticks) return JPG_ERR_CHAIN;
+            std::this_thread::yield();
+        }
+        if (w & (1ull << 47)) return JPG_ERR_CHAIN;
+        whole = w & ((1ull << 47) - 1);
+    }
     if (nbits) *nbits = sl.nbits;
     if (piece_len) *piece_len = sl.scan_len;
     if (bit_offset) *bit_offset = hp.bit_offset;
     if (byte_offset) *byte_offset = (size_t)hp.byte_offset;
-    if (total) *total = ch.rank == 0 ? (size_t)(ch.h_total[par] & ~(1ull << 63)) : 0;
+    if (total) *total = (size_t)whole;
     return JPG_OK;
 }
 

@@ -104,32 +104,29 @@ __global__ __launch_bounds__(256) void k_chain_copy(const ChainParams *params, c
     }
 }
 
-__global__ __launch_bounds__(64) void k_chain_done(ChainPass c, uint64_t *host_total) {
+__global__ __launch_bounds__(64) void k_chain_done(ChainPass c, int collect) {
     __shared__ uint64_t sDone[CHAIN_MAX_RANKS];
     const int lane = threadIdx.x;
     ChainMail *box = c.mail + c.parity * CHAIN_MAX_RANKS;
-    if (lane == 0) {
-        mail_store(&box[c.rank].done, mail_pack(c.tag, (c.params->failed ? DONE_ERROR : 0) | c.params->len));
-    }
-    if (c.rank != 0) return;
-    // collector: every piece has landed when every rank with a stripe has said so
-    const bool need = ((c.active >> lane) & 1) != 0;
+    const uint64_t own = (c.params->failed ? DONE_ERROR : 0) | c.params->len;
+    if (lane == 0) mail_store(&box[c.rank].done, mail_pack(c.tag, own));
+    if (!collect) return;
+    // the last rank with a stripe: every piece has landed when every rank before it has said so
+    const bool need = lane < c.rank && ((c.active >> lane) & 1) != 0;
     bool timeout = false;
     sDone[lane] = mail_wait(&box[lane].done, need, c.tag, c.timeout_ticks, timeout);
     bool bad = __ballot(timeout) != 0;
     __syncthreads();
     if (lane == 0) {
-        uint64_t total = 0;
-        for (int k = 0; k < CHAIN_MAX_RANKS; k++) {
+        uint64_t total = own & (DONE_ERROR - 1);
+        bad = bad || (own & DONE_ERROR);
+        for (int k = 0; k < c.rank; k++) {
             bad = bad || (sDone[k] & DONE_ERROR);
             total += sDone[k] & (DONE_ERROR - 1);
         }
         if (bad) chain_fail(c);
         c.params->total = total;
-        if (host_total) {
-            *host_total = total | (bad ? (1ull << 63) : 0);
-            __threadfence_system();
-        }
+        mail_store(&box[c.rank].total, mail_pack(c.tag, (bad ? DONE_ERROR : 0) | total));
     }
 }
 
@@ -159,9 +156,9 @@ hipError_t launch_chain_copy(const ChainPass &c, const uint8_t *scan, uint8_t *g
     return hipGetLastError();
 }
 
-hipError_t launch_chain_done(const ChainPass &c, uint64_t *host_total, hipStream_t s) {
+hipError_t launch_chain_done(const ChainPass &c, bool collect, hipStream_t s) {
     if (!pass_ok(c)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_chain_done, dim3(1), dim3(64), 0, s, c, host_total);
+    hipLaunchKernelGGL(k_chain_done, dim3(1), dim3(64), 0, s, c, collect ? 1 : 0);
     return hipGetLastError();
 }
 

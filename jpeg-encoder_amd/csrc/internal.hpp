@@ -72,7 +72,8 @@ struct ChainMail {
     uint64_t tail;   // its last min(32, bits) bits, right-aligned
     uint64_t len;    // bytes of its stuffed piece
     uint64_t done;   // the piece lies in the gather buffer: value = error:1 (bit 47) | bytes:47
-    uint64_t pad[3];
+    uint64_t total;  // written by the last rank with a stripe when every piece lies there: error:1 (bit 47) | bytes of the scan:47
+    uint64_t pad[2];
 };
 static_assert(sizeof(ChainMail) == 64, "one record per 64 bytes");
 constexpr size_t CHAIN_MAILBOX_BYTES = 2 * CHAIN_MAX_RANKS * sizeof(ChainMail);
@@ -83,7 +84,7 @@ struct ChainParams {
     uint64_t bit_offset;    // of the stripe in the whole scan
     uint64_t byte_offset;   // of its stuffed piece in the gather buffer
     uint64_t len;           // bytes the copy kernel moves (0 after a failure)
-    uint64_t total;         // collector rank: bytes of the whole scan
+    uint64_t total;         // last rank with a stripe: bytes of the whole scan
     uint32_t failed;        // a wait ran out, or the gather buffer is too small
     uint32_t pad;
 };
@@ -142,9 +143,11 @@ hipError_t launch_chain_place(const ChainPass &c, hipStream_t s);
 hipError_t launch_chain_offset(const ChainPass &c, size_t gather_cap, hipStream_t s);
 // copies params->len bytes of `scan` to gather + params->byte_offset (any alignment; peer or host memory)
 hipError_t launch_chain_copy(const ChainPass &c, const uint8_t *scan, uint8_t *gather, hipStream_t s);
-// publishes "piece in place"; on the collector rank (rank 0) also waits for every rank's and writes the total
-// to params->total and *host_total (page-locked), bit 63 set when any rank failed
-hipError_t launch_chain_done(const ChainPass &c, uint64_t *host_total, hipStream_t s);
+// publishes "piece in place"; the last rank with a stripe (collect) also waits for the same word of every rank before
+// it and publishes the length of the whole scan in its record's `total`, with the error bit when any rank failed.
+// (No kernel of the chain ever waits for a rank above its own: whoever needs the total -- the owner of the gather
+// buffer -- reads that word from the host.)
+hipError_t launch_chain_done(const ChainPass &c, bool collect, hipStream_t s);
 
 
 // e0/e1: optional events that receive the kernel's own start and end time stamps.

@@ -1,5 +1,5 @@
 """Randomised parity run on the GPU box: random sizes, ratios, transforms, contents, row orders, pitches and
-input kinds (host rows, device rows, batches, stripes) through the C ABI, every stuffed scan compared byte for byte with
+input kinds (host rows, device rows, batches, stripes with host exchanges, stripes through the chain) through the C ABI, every stuffed scan compared byte for byte with
 the CPU oracle.  usage: python tools/fuzz_parity.py [cases] [seed]"""
 import os
 import sys
@@ -36,8 +36,37 @@ def content(w, h, kind, stride):
     return rows
 
 
+def chain_scan(rows, w, h, stride, ratio, algo, vs, bottom_up, n):
+    """MCU-row stripes through the stripe chain: n contexts of this process, a pass queued on all of them in rank order."""
+    S = J.stripes
+    plan = S.plan_stripes(h, vs, n)
+    active = [k for k, (a, b) in enumerate(plan) if b > a]
+    mask = sum(1 << k for k in active)
+    cap = max(1 << 16, w * h * 4)
+    mailbox, gather = L.jpg_chain_mailbox_alloc(), L.jpg_device_alloc(0, cap)
+    es, dev = {}, {}
+    for k in active:
+        es[k] = J.Encoder(ratio, algo)
+        es[k].chain_setup(k, n, mailbox, gather, cap)
+        dev[k] = torch.from_numpy(np.ascontiguousarray(S.stripe_rows(rows, h, plan[k][0], plan[k][1], bottom_up))).cuda()
+    torch.cuda.synchronize()
+    for k in active:
+        es[k].stripe_device(dev[k].data_ptr(), w, plan[k][1] - plan[k][0], stride, bottom_up)
+        es[k].chain_pass_async(mask)
+    res = {k: es[k].chain_pass_finish() for k in reversed(active)}
+    total = res[0][4]
+    out = np.zeros(total, np.uint8)
+    if total:
+        J._native.check(None, L.jpg_device_to_host(0, out.ctypes.data, gather, total))
+    for e in es.values():
+        e.close()
+    L.jpg_device_free(0, gather)
+    L.jpg_free(mailbox)
+    return out
+
+
 t0 = time.time()
-done = fused = static = 0
+done = fused = static = chained = 0
 import ctypes as C  # noqa: E402
 L = J._native.lib()
 for it in range(cases):
@@ -58,8 +87,12 @@ for it in range(cases):
     rows = content(w, h, kind, stride)
     want = refcpu.RefImage.from_bgr(rows, w, h, stride, ratio, ref_algo, bottom_up=bottom_up).encode().stuffed_scan()
     enc = encs.setdefault((ratio, algo), J.Encoder(ratio, algo))
-    mode = int(rng.integers(5))
-    if mode == 3:
+    mode = int(rng.integers(6))
+    tile_w = 1024 if (hs, vs) == (2, 1) else 512
+    if mode == 5 and w >= tile_w:
+        got = chain_scan(rows, w, h, stride, ratio, algo, vs, bottom_up, int(rng.integers(1, 7)))
+        chained += 1
+    elif mode == 3 or mode == 5:
         # MCU-row stripes on separate contexts, stitched
         n = int(rng.integers(2, 6))
         jobs = [J.stripes.StripeJob(J.Encoder(ratio, algo), k, n, rows, w, h, stride, vs, bottom_up) for k in range(n)]
@@ -113,4 +146,5 @@ for it in range(cases):
     fused += int(enc.fused_coding())
     if it % 25 == 24:
         print("%d cases ok (%d through the fused coding kernel), %.0f s" % (done, fused, time.time() - t0), flush=True)
-print("fuzz ok: %d cases, %d through the fused coding kernel, %d through the entry point that allocates nothing" % (done, fused, static))
+print("fuzz ok: %d cases, %d through the fused coding kernel, %d through the entry point that allocates nothing, %d through the stripe chain"
+      % (done, fused, static, chained))
