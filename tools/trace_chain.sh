@@ -14,14 +14,16 @@ rows = []
 for p in glob.glob(sys.argv[1] + "/*kernel_trace.csv"):
     for r in csv.DictReader(open(p)):
         if "jpg::" in r["Kernel_Name"]:
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void jpg::", "")[:40],
-                         r.get("Queue_Id", "?")))
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("jpg::", "")
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name.split("(")[0][:40], r.get("Queue_Id", "?")))
 rows.sort()
 n = int(sys.argv[2])
-per_pass = 9 * n                      # kernels of one pass: 9 per stripe
-last = rows[-per_pass:]
+# kernels of one pass: 8 per stripe (k_mcu_dc, k_coded, k_tail, k_chain_place, k_stream, k_chain_offset, k_chain_copy,
+# k_chain_done); the last pass starts at the n-th last k_mcu_dc
+starts = [i for i, r in enumerate(rows) if r[2].startswith("k_mcu_dc")]
+last = rows[starts[-n]:]
 t0 = last[0][0]
-print("kernels of the last pass of %d stripes (us from the first kernel's start): start, end, duration, queue, kernel" % n)
+print("kernels of the last pass of %d stripes under rocprofv3 --kernel-trace (us from the first kernel's start): start, end, duration, queue, kernel" % n)
 for s, e, name, q in last:
     print("%9.1f %9.1f  %7.1f us  q%-3s %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q, name))
 print("pass: %.1f us from the first kernel's start to the last kernel's end" % ((max(e for _, e, _, _ in last) - t0) / 1e3))
