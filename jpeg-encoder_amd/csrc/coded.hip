@@ -168,7 +168,7 @@ __device__ __forceinline__ void coded_tile(const CodedArgs &a) {
     if (tid == 0) clen_out[(uint32_t)img * k_cstride + (uint32_t)tile] = sY[5] & 1;
     return;
 #endif
-    tile_transform<HS, VS, ALGO>(lds, mcus, tid, [&] {
+    tile_transform<HS, VS, ALGO, (C::TW == 512)>(lds, mcus, tid, [&] {
         if (!has_halo) {
             // first tile of the image: the caller's predictors, left where the coders look for the MCU before the tile
             if (lane < 3) sHaloDc[lane] = a.pred_dev ? a.pred_dev[lane] : (lane == 0 ? a.pred[0] : (lane == 1 ? a.pred[1] : a.pred[2]));

@@ -407,7 +407,9 @@ __device__ __forceinline__ void halo_dc_sums(const uint8_t *hY, const uint8_t *h
 // planes' space being reused) the finished blocks to lds[bi * OUT_STRIDE], bi = position of the block
 // in the scan order of the tile.  The last wave also runs spare(); except at 4:2:2 it has no block to transform.
 // Contains one barrier; the caller places one after it.
-template <int HS, int VS, int ALGO, class Spare>
+// ROWS_ONCE (real-dct): the first pass, which is the same for luma and chroma blocks, is written once ahead of the
+// branch on the component, with the samples kept in f32 (rows_real<true>).
+template <int HS, int VS, int ALGO, bool ROWS_ONCE = false, class Spare>
 __device__ __forceinline__ void tile_transform(uint8_t *lds, int mcus, int tid, Spare spare) {
     using C = TileCfg<HS, VS>;
     const uint8_t *sY = lds;
@@ -449,8 +451,15 @@ __device__ __forceinline__ void tile_transform(uint8_t *lds, int mcus, int tid, 
     __syncthreads();   // every sample is in registers: the planes' space becomes the output staging area
     if (bi >= 0) {
         uint32_t *slot = reinterpret_cast<uint32_t *>(&lds[bi * OUT_STRIDE]);
-        if (wave < C::YWAVES) transform_block<ALGO, false>(px, slot);
-        else transform_block<ALGO, true>(px, slot);
+        if constexpr (ALGO == ALGO_REAL && ROWS_ONCE) {
+            float t[8][8];
+            rows_real<true>(px, t);
+            if (wave < C::YWAVES) columns_real<false>(t, slot);
+            else columns_real<true>(t, slot);
+        } else {
+            if (wave < C::YWAVES) transform_block<ALGO, false>(px, slot);
+            else transform_block<ALGO, true>(px, slot);
+        }
     }
     if (wave == C::SPARE_WAVE) spare();
 }
