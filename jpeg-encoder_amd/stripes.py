@@ -286,6 +286,34 @@ class DeviceGather:
             self.own, self.own_cap = None, 0
 
 
+def share_from_rank0(ex, alloc, free, export, open_, close):
+    """One allocation of rank 0 made reachable on every rank, or on none: rank 0 allocates (alloc() -> address or None)
+    and exports (export(address) -> 8 int64 or None), the others open (open_(words) -> address or None); the ranks
+    then tell each other whether they got it.  If any did not, those that did let go again (close(address) on the
+    others, free(address) on rank 0 once nobody has it mapped) and every rank returns None: the decision is the same
+    on all ranks, so they can fall back together.  `ex`: rank, world, all_gather(values), barrier()."""
+    ok, words, mine = 1, [0] * 8, None
+    if ex.rank == 0:
+        mine = alloc()
+        words = export(mine) if mine else None
+        ok = int(bool(mine) and words is not None)
+        words = words or [0] * 8
+    got = ex.all_gather([ok] + list(words))
+    ok, addr = int(got[0][0]), mine
+    if ok and ex.rank != 0:
+        addr = open_(list(got[0][1:]))
+        ok = int(addr is not None)
+    everyone = min(int(g[0]) for g in ex.all_gather([ok]))
+    if everyone:
+        return addr
+    if ex.rank != 0 and ok and addr:
+        close(addr)
+    ex.barrier()                          # no rank has it mapped any more
+    if ex.rank == 0 and mine:
+        free(mine)
+    return None
+
+
 class StripeChain:
     """One process per GPU: the set-up of the stripe chain (jpg_chain_* in include/jpeg_hip.h), in which the ranks'
     kernels hand each other the scalars of a pass through a mailbox in host memory and put the stuffed pieces at
@@ -324,34 +352,28 @@ class StripeChain:
         not get at it (every rank then lets go of it again)."""
         import ctypes as C
         N = self.N
-        ok, words, mine = 1, [0] * 8, None
-        if self.rank == 0:
-            mine = alloc()
+
+        def export(p):
             h = (C.c_uint8 * N.IPC_HANDLE_BYTES)()
-            ok = int(bool(mine) and self.L.jpg_ipc_export(mine, h) == 0)
-            words = [int(x) for x in np.frombuffer(bytes(h), np.int64)]
-        got = self.ex.all_gather([ok] + words)
-        ok, addr = got[0][0], mine
-        if ok and self.rank != 0:
-            h = (C.c_uint8 * N.IPC_HANDLE_BYTES).from_buffer_copy(np.array(got[0][1:], np.int64).tobytes())
+            if self.L.jpg_ipc_export(p, h) != 0:
+                return None
+            return [int(x) for x in np.frombuffer(bytes(h), np.int64)]
+
+        def open_(words):
+            h = (C.c_uint8 * N.IPC_HANDLE_BYTES).from_buffer_copy(np.array(words, np.int64).tobytes())
             p = C.c_void_p()
-            ok = int(self.L.jpg_ipc_open(self.device, h, C.byref(p)) == 0 and bool(p.value))
-            addr = p.value if ok else None
-        everyone = min(g[0] for g in self.ex.all_gather([ok]))
-        if everyone:
-            if self.rank == 0:
-                self._mine.append((mine, free))
-            else:
-                self._opened.append(addr)
-            return addr
-        if self.rank != 0 and addr:
-            self.L.jpg_ipc_close(addr)
-        self.ex.barrier()                 # no rank has it mapped any more
-        if mine:
-            free(mine)
-        if required:
-            raise RuntimeError("memory of rank 0 cannot be opened on every rank through an inter-process handle")
-        return None
+            return p.value if self.L.jpg_ipc_open(self.device, h, C.byref(p)) == 0 and p.value else None
+
+        addr = share_from_rank0(self.ex, alloc, free, export, open_, self.L.jpg_ipc_close)
+        if addr is None:
+            if required:
+                raise RuntimeError("memory of rank 0 cannot be opened on every rank through an inter-process handle")
+            return None
+        if self.rank == 0:
+            self._mine.append((addr, free))
+        else:
+            self._opened.append(addr)
+        return addr
 
     def encode_async(self, width, height, stride, v, stripe_ptr=None, rows=None, bottom_up=True):
         """Queues one pass: this rank's stripe (device rows at stripe_ptr, or sliced out of the host array `rows` of the

@@ -124,3 +124,69 @@ def test_two_processes_over_gloo(tmp_path):
         port = s.getsockname()[1]
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert int(open(tmp_path / "ok").read()) > 0
+
+
+class _ThreadExchange:
+    """all_gather / barrier among the threads of one process (the interface of ScalarExchange)."""
+
+    def __init__(self, rank, world, shared):
+        self.rank, self.world, self.shared = rank, world, shared
+
+    def all_gather(self, values):
+        import threading
+        sh = self.shared
+        with sh["cv"]:
+            gen = sh["gen"]
+            sh["slots"][self.rank] = tuple(int(v) for v in values)
+            sh["count"] += 1
+            if sh["count"] == self.world:
+                sh["result"] = list(sh["slots"])
+                sh["count"] = 0
+                sh["gen"] += 1
+                sh["cv"].notify_all()
+            else:
+                while sh["gen"] == gen:
+                    assert sh["cv"].wait(timeout=30)
+            return list(sh["result"])
+
+    def barrier(self):
+        self.all_gather([])
+
+
+@pytest.mark.parametrize("failing", [None, 0, 2, "export"])
+def test_sharing_rank0_memory_is_decided_by_all_ranks_together(J, failing):
+    """The set-up step of the stripe chain that makes an allocation of rank 0 reachable on every rank: when one rank
+    cannot open it (or rank 0 cannot allocate or export it) EVERY rank gets None -- so all fall back to the next kind
+    of memory together -- those that had opened it have closed it, and rank 0 frees it only after that."""
+    import threading
+    S = J.stripes
+    world = 4
+    shared = {"cv": threading.Condition(), "slots": [None] * world, "count": 0, "gen": 0, "result": None}
+    log, out = [], [None] * world
+
+    def run(rank):
+        ex = _ThreadExchange(rank, world, shared)
+        alloc = lambda: (None if failing == 0 else 0x1000)
+        export = lambda p: (None if failing == "export" else [7, 0, 0, 0, 0, 0, 0, 1])
+        open_ = lambda words: (None if rank == failing else 0x2000 + rank if words == [7, 0, 0, 0, 0, 0, 0, 1] else None)
+        out[rank] = S.share_from_rank0(ex, alloc, lambda p: log.append(("free", rank, p)), export, open_,
+                                       lambda p: log.append(("close", rank, p)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    if failing is None:
+        assert out == [0x1000, 0x2001, 0x2002, 0x2003] and log == []
+    else:
+        assert out == [None] * world
+        closes = [e for e in log if e[0] == "close"]
+        frees = [e for e in log if e[0] == "free"]
+        if failing == 2:
+            assert sorted(closes) == [("close", 1, 0x2001), ("close", 3, 0x2003)]
+            assert frees == [("free", 0, 0x1000)] and log.index(frees[0]) > max(log.index(c) for c in closes)
+        elif failing == "export":
+            assert closes == [] and frees == [("free", 0, 0x1000)]
+        else:
+            assert log == []
