@@ -579,7 +579,7 @@ def main():
             cfg = {"workload": "%dx%d BMP, %s, %s, MCU-row stripes" % (W, H, args.ratio, args.dct_algorithm),
                    "named_config": args.config, "encodes_of_the_image_per_step": args.passes,
                    "stripes": world, "stripe_rows_rank0": J.stripes.plan_stripes(H, vs, world)[0][1],
-                   "stripe_protocol": protocol, "gather": chain.gather if chain else "device",
+                   "stripe_protocol": protocol, "gather": chain.gather if chain else gather.kind,
                    "passes_in_flight": 2 if chain else 1, "control_plane": control if world > 1 else None,
                    "parallelism": ("MCU-row stripes x%d, scalars handed on by the kernels through a mailbox in host memory, "
                                    "pieces copied to their offsets by a kernel" if chain else
@@ -641,7 +641,10 @@ def main():
             if not np.array_equal(got, want):
                 raise SystemExit("stitched scan differs from the whole-image encode")
             print("verified: %d stitched bytes equal the whole-image scan" % got.size, file=sys.stderr, flush=True)
-        (chain or gather).close()
+        if chain:
+            chain.close()
+        else:
+            gather.close(ex)
         ex.close()
     if world > 1:
         dist.destroy_process_group()

@@ -228,7 +228,7 @@ int jpg_stitch_finish(jpg_ctx *ctx, size_t *len, uint8_t *tail);
  * queued on the context's stream (jpg_sync waits).  dst_device >= 0 and different from the context's device:
  * a peer copy between the two GPUs (hipMemcpyPeerAsync, over xGMI where the GPUs are linked); dst_device < 0 or
  * the same device: `dst` is any address this process can write by unified addressing, e.g. a buffer of
- * another process opened with jpg_ipc_open.  cap = bytes available at dst. */
+ * another process opened with jpg_ipc_open, or page-locked host memory.  cap = bytes available at dst. */
 int jpg_scan_copy_to_device(jpg_ctx *ctx, void *dst, int dst_device, size_t cap);
 /* Plain device memory for the gathered scan, for hosts that do not link the HIP runtime themselves, a blocking
  * copy of it to the host (waits for everything queued on the device first), and its hand-over between

@@ -894,8 +894,9 @@ extern "C" int jpg_scan_copy_to_device(jpg_ctx *c, void *dst, int dst_device, si
     DeviceGuard dg;
     if (int e = use_device(c, dg)) return e;
     if (dst_device < 0 || dst_device == c->device) {
-        // the same device, or memory of another process opened with jpg_ipc_open (unified addressing finds it)
-        HIP_TRY(c, hipMemcpyAsync(dst, sl.eb.scan, sl.scan_len, hipMemcpyDeviceToDevice, c->stream));
+        // the same device, memory of another process opened with jpg_ipc_open, or page-locked host memory (unified
+        // addressing finds out which)
+        HIP_TRY(c, hipMemcpyAsync(dst, sl.eb.scan, sl.scan_len, hipMemcpyDefault, c->stream));
     } else {
         HIP_TRY(c, hipMemcpyPeerAsync(dst, dst_device, sl.eb.scan, c->device, sl.scan_len, c->stream));
     }

@@ -215,75 +215,77 @@ class ShmExchange:
 
 
 class DeviceGather:
-    """Where the stuffed pieces of all ranks meet: a device buffer owned by rank 0, which the other ranks open
-    through an inter-process memory handle and write their pieces into at their byte offsets with a
-    device-to-device copy (over xGMI between GPUs).  No collective moves scan bytes.  Kept across calls."""
+    """Where the stuffed pieces of all ranks meet (the protocol with host exchanges): a buffer owned by rank 0 that
+    the other ranks open through an inter-process handle and write their pieces into at their byte offsets with a
+    device-to-device copy (over xGMI between GPUs).  Device memory of rank 0 where every rank can open that
+    (`kind == "device"`), else page-locked host memory of rank 0 (`kind == "host"`: the pieces travel over PCIe).
+    No collective moves scan bytes.  Kept across calls; grown, by all ranks together, when a scan does not fit."""
 
     def __init__(self, native, device):
         self.N, self.device = native, device
         self.L = native.lib()
-        self.own, self.own_cap = None, 0          # rank 0: the buffer
-        self.words = None                         # ... and its exported handle as 8 int64
-        self.opened = {}                          # other ranks: handle bytes -> device address in this process
-        self.retired = []                         # rank 0: outgrown buffers the other ranks may still have mapped
+        self.cap, self.kind = 0, None
+        self.buffer = None                        # the buffer's address in this process
+        self._free = None                         # rank 0: how to release it
 
-    def handle_words(self, cap):
-        """Rank 0: (re)allocate for cap bytes and return the handle as 8 int64; others pass zeros."""
+    def ensure(self, ex, cap):
+        """Collective: every rank calls it with the same cap.  (Re)allocates when cap exceeds the present size."""
         import ctypes as C
-        if cap > self.own_cap:
-            if self.own:
-                self.retired.append(self.own)             # still mapped by the other ranks: freed by release_retired()
-            cap = max(cap, 1 << 20)
-            self.own = self.L.jpg_device_alloc(self.device, cap)
-            if not self.own:
-                raise MemoryError("jpg_device_alloc(%d)" % cap)
-            self.own_cap = cap
-            self.words = None
-        if self.words is None:
-            h = (C.c_uint8 * self.N.IPC_HANDLE_BYTES)()
-            self.N.check(None, self.L.jpg_ipc_export(self.own, h))
-            self.words = [int(x) for x in np.frombuffer(bytes(h), np.int64)]
-        return self.words
+        if cap <= self.cap:
+            return
+        self.release(ex)
+        cap = max(int(cap), 1 << 20)
+        N, L, dev = self.N, self.L, self.device
 
-    def address(self, words):
-        """The gather buffer's address in this process (rank 0: its own allocation)."""
-        import ctypes as C
-        if self.own:
-            return self.own
-        raw = np.array(words, np.int64).tobytes()
-        if raw not in self.opened:
-            # a new handle means rank 0 has outgrown the buffer this process had mapped: that mapping is closed
-            # before the barrier that lets rank 0 free the old allocation (encode_striped)
-            for p in self.opened.values():
-                self.L.jpg_ipc_close(p)
-            self.opened = {}
-            h = (C.c_uint8 * self.N.IPC_HANDLE_BYTES).from_buffer_copy(raw)
+        def export(p):
+            h = (C.c_uint8 * N.IPC_HANDLE_BYTES)()
+            return [int(x) for x in np.frombuffer(bytes(h), np.int64)] if L.jpg_ipc_export(p, h) == 0 else None
+
+        def open_(words):
+            h = (C.c_uint8 * N.IPC_HANDLE_BYTES).from_buffer_copy(np.array(words, np.int64).tobytes())
             p = C.c_void_p()
-            self.N.check(None, self.L.jpg_ipc_open(self.device, h, C.byref(p)))
-            self.opened[raw] = p.value
-        return self.opened[raw]
+            return p.value if L.jpg_ipc_open(dev, h, C.byref(p)) == 0 and p.value else None
 
-    def release_retired(self):
-        """Rank 0, after a barrier behind the exchange that announced the new handle (every rank has closed its
-        mapping of the old buffers by then)."""
-        for p in self.retired:
-            self.L.jpg_device_free(self.device, p)
-        self.retired = []
+        for kind, alloc, free in (("device", lambda: L.jpg_device_alloc(dev, cap), lambda p: L.jpg_device_free(dev, p)),
+                                  ("host", lambda: L.jpg_host_alloc(cap), L.jpg_free)):
+            addr = share_from_rank0(ex, alloc, free, export, open_, L.jpg_ipc_close)
+            if addr is not None:
+                self.buffer, self.cap, self.kind = addr, cap, kind
+                self._free = free if ex.rank == 0 else None
+                return
+        raise RuntimeError("no memory of rank 0 can be opened on every rank")
+
+    def release(self, ex):
+        """Collective: every rank lets go of the buffer, then rank 0 frees it."""
+        if self.buffer is None:
+            return
+        if ex.rank != 0:
+            self.L.jpg_ipc_close(self.buffer)
+        ex.barrier()                              # no rank has it mapped any more
+        if ex.rank == 0:
+            self._free(self.buffer)
+        self.buffer, self.cap, self.kind = None, 0, None
 
     def read(self, n):
+        """Rank 0: the first n bytes of the buffer."""
+        import ctypes as C
         out = np.zeros(n, np.uint8)
-        if n:
-            self.N.check(None, self.L.jpg_device_to_host(self.device, out.ctypes.data, self.own, n))
+        if n and self.kind == "device":
+            self.N.check(None, self.L.jpg_device_to_host(self.device, out.ctypes.data, self.buffer, n))
+        elif n:
+            C.memmove(out.ctypes.data, self.buffer, n)
         return out
 
-    def close(self):
-        for p in self.opened.values():
-            self.L.jpg_ipc_close(p)
-        self.opened = {}
-        self.release_retired()
-        if self.own:
-            self.L.jpg_device_free(self.device, self.own)
-            self.own, self.own_cap = None, 0
+    def close(self, ex=None):
+        """With the exchange: collective, as release().  Without: this rank's side only (rank 0 must be the last)."""
+        if ex is not None:
+            self.release(ex)
+        elif self.buffer is not None:
+            if self._free:
+                self._free(self.buffer)
+            else:
+                self.L.jpg_ipc_close(self.buffer)
+            self.buffer, self.cap, self.kind = None, 0, None
 
 
 def share_from_rank0(ex, alloc, free, export, open_, close):
@@ -441,21 +443,22 @@ def encode_striped(backend, rows, width, height, stride, v, bottom_up=True, grou
     on_device = hasattr(backend, "scan_copy_to_device")
     if on_device:
         from . import _native
+        own_gather = gather is None
         gather = gather or DeviceGather(_native, backend.device)
         n = job.place_on_device(codes)
         bound = 2 * ((sum(c[0] for c in codes) + 7) // 8) + 16 * world       # every byte stuffed, at worst
-        words = gather.handle_words(bound) if rank == 0 else [0] * 8
-        got = ex.all_gather([n] + words)
-        lens = [g[0] for g in got]
-        base = gather.address(got[0][1:])
+        gather.ensure(ex, bound)                                 # (every rank computes the same bound)
+        lens = [g[0] for g in ex.all_gather([n])]
         if n:
-            backend.scan_copy_to_device(base + sum(lens[:rank]), -1, n)
+            backend.scan_copy_to_device(gather.buffer + sum(lens[:rank]), -1, n)
         backend.sync()
         ex.barrier()                                             # every piece has landed
-        gather.release_retired()                                 # (and every rank has let go of an outgrown buffer)
-        if rank != 0:
-            return None
-        return gather.read(sum(lens)) if fetch else sum(lens)
+        out = None
+        if rank == 0:
+            out = gather.read(sum(lens)) if fetch or own_gather else sum(lens)
+        if own_gather:
+            gather.close(ex)                                     # (a buffer made for this call goes with it)
+        return out
     import torch
     import torch.distributed as dist
     pgroup = getattr(ex, "group", None)                              # (a ShmExchange has none: the default group)
