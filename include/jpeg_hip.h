@@ -260,18 +260,27 @@ int jpg_ipc_close(void *dev_ptr);
  *  - gather: where the whole stuffed scan is put together: device memory of the collector rank 0 (the other
  *    ranks pass the address they reach it by: the same pointer within a process once jpg_peer_access(device,
  *    owner) returned 1, the result of jpg_ipc_open between processes), or, where GPUs cannot reach each other's
- *    memory, page-locked / registered host memory.  gather_cap: its size; a scan that does not fit fails the pass.
+ *    memory, page-locked host memory.  gather_cap: its size.  The buffer has two halves of gather_cap / 2 bytes:
+ *    passes with an even number (counted from jpg_chain_setup) put their scan at the start of the first half,
+ *    those with an odd number at the start of the second; a scan that does not fit its half fails the pass.
  *  - jpg_chain_setup binds both to the context and restarts the pass counter: every rank calls it before the
- *    first pass, with its rank (0 .. world-1, world <= 64), and all ranks run the same number of passes.
+ *    first pass, with its rank (0 .. world-1, world <= 64), and all ranks run the same number of passes.  Rank 0's
+ *    call clears the mailbox (through the host address it was given): no rank queues a pass before that call
+ *    has returned, and none is still running one of an earlier set-up.
  *  - jpg_chain_pass_async: after jpg_stripe_device / jpg_stripe_host_async has named the stripe's rows (images
- *    at least one tile wide: JPG_ERR_STATE otherwise), queues the whole pass on the context's stream and
- *    returns.  active_mask: bit k set when rank k has a stripe (ranks without rows make no call).
+ *    at least one tile wide: JPG_ERR_STATE otherwise), queues the whole pass on the context's stream and returns.  active_mask: bit k set when rank k has a stripe (ranks without rows make no call; rank 0 always
+ *    has one: JPG_ERR_BAD_ARG otherwise).
  *    One process driving several contexts queues the ranks in ascending order, all of them before it waits for
  *    any: a gate only waits for lower ranks, so nothing queued can wait for something behind it in a hardware queue.
- *    Two passes may be queued before the first is taken (the host queues one while the other runs); a third is
- *    refused with JPG_ERR_STATE.
+ *    Two passes may be queued before the first is taken; a third is refused with JPG_ERR_STATE.  Each pass in
+ *    flight has its own hand-over record in the mailbox (four records, used in turn: a rank that queues pass p
+ *    has taken pass p-2, which the ranks below it had coded after rank 0 took pass p-4, so nobody reads the record
+ *    any more), its own half of the gather buffer and its own set of the context's working buffers.  The rows of a
+ *    stripe stay the caller's until its pass is taken.  Rank 0 has read, or given up, the scan of pass p-2 when it
+ *    queues pass p: that pass fills the same half.
  *  - jpg_chain_pass_finish waits for the context's oldest queued pass: the stripe's bit count, the length of its stuffed
- *    piece, where its bits and its piece start, and on rank 0 the length of the whole scan (0 elsewhere): the last
+ *    piece, where its bits start in the scan and its piece in the gather buffer (the half's offset included), and
+ *    on rank 0 the length of the whole scan (0 elsewhere): the last
  *    rank with a stripe publishes it in the mailbox when every piece lies in the gather buffer, and rank 0's call
  *    waits for that word on the host -- rank 0 therefore passes a mailbox address its host can read (its own
  *    allocation).  Any of the pointers may be NULL. */

@@ -103,11 +103,12 @@ struct jpg_ctx {
         const ChainMail *mail_host = nullptr;   // the address the host reads it by (rank 0 only needs it)
         uint8_t *gather = nullptr; size_t gather_cap = 0;
         int rank = 0, world = 0;
-        ChainParams *d_params = nullptr;    // device
+        ChainParams *d_params = nullptr;    // device, [2]: one per pass in flight (parity of the pass number)
         // Two passes may be queued before the first is taken: the page-locked records a pass reports through exist
         // twice, indexed by the parity of the pass number
         ChainParams *h_params = nullptr;    // [2] copies of d_params, made at the end of a pass
         int last_of[2] = {0, 0};            // the last rank with a stripe in the pass: it publishes the scan's length
+        int slot_of[2] = {0, 0};            // the context's set of back-end buffers the pass used
         DevStatus *h_status = nullptr;      // [2] status records of the passes
         hipEvent_t ev[2] = {nullptr, nullptr};   // end of a pass
         uint32_t epoch_of[2] = {0, 0};      // epoch the pass's errors are tagged with
@@ -1033,12 +1034,12 @@ extern "C" int jpg_chain_setup(jpg_ctx *c, int rank, int world, void *mailbox, v
     void *mail_dev = nullptr, *gather_dev = nullptr;
     if (int e = device_address_of_host(c, mailbox, &mail_dev)) return e;
     if (int e = device_address_of_host(c, gather, &gather_dev)) return e;
-    if (!ch.d_params) HIP_TRY(c, hipMalloc((void **)&ch.d_params, sizeof(ChainParams)));
+    if (!ch.d_params) HIP_TRY(c, hipMalloc((void **)&ch.d_params, 2 * sizeof(ChainParams)));
     if (!ch.h_params) HIP_TRY(c, hipHostMalloc((void **)&ch.h_params, 2 * sizeof(ChainParams), hipHostMallocDefault));
     if (!ch.h_status) HIP_TRY(c, hipHostMalloc((void **)&ch.h_status, 2 * sizeof(DevStatus), hipHostMallocDefault));
     for (hipEvent_t &e : ch.ev)
         if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(c, hipMemset(ch.d_params, 0, sizeof(ChainParams)));
+    HIP_TRY(c, hipMemset(ch.d_params, 0, 2 * sizeof(ChainParams)));
     memset(ch.h_params, 0, 2 * sizeof(ChainParams));
     memset(ch.h_status, 0, 2 * sizeof(DevStatus));
     ch.mail = static_cast<ChainMail *>(mail_dev);
@@ -1048,6 +1049,8 @@ extern "C" int jpg_chain_setup(jpg_ctx *c, int rank, int world, void *mailbox, v
     ch.rank = rank; ch.world = world;
     ch.pass = 0;
     ch.taken = 0;
+    // the pass numbers start again: what earlier passes left in the records must not be taken for theirs
+    if (rank == 0) memset(mailbox, 0, CHAIN_MAILBOX_BYTES);
     // how long a gate waits for another rank before the pass fails (wall clock of the device, 100 MHz)
     long ms = 10000;
     if (const char *ev = getenv("JPG_CHAIN_TIMEOUT_MS")) ms = atol(ev) > 0 ? atol(ev) : ms;
@@ -1062,16 +1065,21 @@ extern "C" int jpg_chain_pass_async(jpg_ctx *c, uint64_t active_mask) {
     if (c->stage < ST_COEF || !code_from_rows(c)) return JPG_ERR_STATE;   // a loaded stripe the coding kernel takes
     if (ch.pass - ch.taken >= 2) return JPG_ERR_STATE;                    // two passes are queued already: take one first
     if (!((active_mask >> ch.rank) & 1)) return JPG_ERR_BAD_ARG;
+    if (!(active_mask & 1)) return JPG_ERR_BAD_ARG;    // rank 0 takes part in every pass: it paces the others
     if (ch.world < 64 && (active_mask >> ch.world)) return JPG_ERR_BAD_ARG;
     DeviceGuard dg;
     if (int e = use_device(c, dg)) return e;
     c->npend = 0;
+    // Two passes may be in flight: each has its own hand-over record, its own half of the gather buffer and its own
+    // set of back-end buffers (slots 0 and 1 of the context), all picked by the parity of the pass number.
     const int par = (int)(ch.pass & 1);
+    c->cur = par;
     S(c).h_status_alt = &ch.h_status[par];
     if (int e = prepare_slot(c, true)) { S(c).h_status_alt = nullptr; return e; }
     jpg_ctx::Slot &sl = S(c);
     ch.epoch_of[par] = sl.eb.epoch;
     ch.nchunks_of[par] = sl.eb.nchunks;
+    ch.slot_of[par] = c->cur;
     int pred_rank = -1, last_rank = ch.rank;
     for (int k = 0; k < ch.world; k++) {
         if (!((active_mask >> k) & 1)) continue;
@@ -1079,32 +1087,40 @@ extern "C" int jpg_chain_pass_async(jpg_ctx *c, uint64_t active_mask) {
         last_rank = k > last_rank ? k : last_rank;
     }
     const uint64_t pass = ch.pass++;
-    const ChainPass cp{ch.mail, ch.d_params, sl.eb.status, sl.eb.epoch, 0x8000u | (uint32_t)(pass & 0x7fff), (int)(pass & 1),
-                       ch.rank, pred_rank, active_mask, ch.timeout_ticks};
+    ChainParams *params = ch.d_params + par;
+    const ChainPass cp{ch.mail, params, sl.eb.status, sl.eb.epoch, 0x8000u | (uint32_t)(pass & 0x7fff),
+                       (int)(pass % CHAIN_SLOTS), ch.rank, pred_rank, active_mask, ch.timeout_ticks};
+    const size_t half = ch.gather_cap / 2;
+    // (One stream: putting the second half of a pass on the context's second stream, beside the coding of the next
+    // pass, was measured and gains nothing -- the coding kernel slows down by what the stuffing takes.)
+    const hipStream_t sa = c->stream, sb = c->stream;
     // the stripe's last DC coefficients (straight from its last MCU's pixels), published; the predecessor's fetched
-    HIP_TRY(c, launch_last_dc_pixels(c->g, c->algo, c->d_src, c->d_dc, c->stream, &cp));
-    sl.eb.chain = ch.d_params;
-    sl.eb.chain_slot = ch.mail + cp.parity * CHAIN_MAX_RANKS + ch.rank;
+    HIP_TRY(c, launch_last_dc_pixels(c->g, c->algo, c->d_src, c->d_dc, sa, &cp));
+    sl.eb.chain = params;
+    sl.eb.chain_slot = ch.mail + cp.slot * CHAIN_MAX_RANKS + ch.rank;
     sl.eb.chain_tag = cp.tag;
     int e = launch_timed(c, 1, [&](hipEvent_t e0, hipEvent_t e1) {
-        return launch_coded(c->g, c->algo, c->d_src, nullptr, 1, ZERO_PRED, sl.eb, c->stream, e0, e1);
+        return launch_coded(c->g, c->algo, c->d_src, nullptr, 1, ZERO_PRED, sl.eb, sa, e0, e1);
     });
     hipError_t he = hipSuccess;
     if (!e) {
-        he = launch_tail(sl.eb, c->stream);                    // bit count and last bits, published
+        he = launch_tail(sl.eb, sa);                           // bit count and last bits, published
         sl.tail_known = he == hipSuccess;
-        if (he == hipSuccess) he = launch_chain_place(cp, c->stream);
+        if (he == hipSuccess) he = launch_chain_place(cp, sb);
     }
-    if (!e && he == hipSuccess) e = queue_stuff(c, 0, 0, ch.rank == last_rank, c->stream);   // shift and head bits from the gate
+    if (!e && he == hipSuccess) e = queue_stuff(c, 0, 0, ch.rank == last_rank, sb);   // shift and head bits from the gate
     sl.eb.chain = nullptr; sl.eb.chain_slot = nullptr; sl.eb.chain_tag = 0;
     sl.h_status_alt = nullptr;
     // (a pass that could not be queued whole still counts: the ranks number their passes alike, and its gates run dry)
-    if (!e && he == hipSuccess) he = launch_chain_offset(cp, ch.gather_cap, c->stream);
-    if (!e && he == hipSuccess) he = launch_chain_copy(cp, sl.eb.scan, ch.gather, c->stream);
+    if (!e && he == hipSuccess) he = launch_chain_offset(cp, half, sb);
+    if (!e && he == hipSuccess) he = launch_chain_copy(cp, sl.eb.scan, ch.gather + (size_t)par * half, sb);
     ch.last_of[par] = last_rank;
-    if (!e && he == hipSuccess) he = launch_chain_done(cp, ch.rank == last_rank, c->stream);
-    if (!e && he == hipSuccess) he = hipMemcpyAsync(&ch.h_params[par], ch.d_params, sizeof(ChainParams), hipMemcpyDeviceToHost, c->stream);
-    (void)hipEventRecord(ch.ev[par], c->stream);
+    if (!e && he == hipSuccess) he = launch_chain_done(cp, ch.rank == last_rank, sb);
+    if (!e && he == hipSuccess) he = hipMemcpyAsync(&ch.h_params[par], params, sizeof(ChainParams), hipMemcpyDeviceToHost, sb);
+    // the set of buffers is free again when the piece has been copied out of it (prepare_slot waits for this event)
+    (void)hipEventRecord(sl.s_done, sb);
+    sl.busy = true;
+    (void)hipEventRecord(ch.ev[par], sb);
     if (e) return e;
     HIP_TRY(c, he);
     return JPG_OK;
@@ -1120,7 +1136,8 @@ extern "C" int jpg_chain_pass_finish(jpg_ctx *c, uint64_t *nbits, size_t *piece_
     const int par = (int)(ch.taken & 1);                         // the oldest pass not handed out yet
     HIP_TRY(c, hipEventSynchronize(ch.ev[par]));
     ch.taken++;
-    jpg_ctx::Slot &sl = S(c);
+    jpg_ctx::Slot &sl = c->slot[ch.slot_of[par]];
+    c->view = ch.slot_of[par];
     const DevStatus &hs = ch.h_status[par];
     {
         const int v = -hs.error;
@@ -1137,7 +1154,7 @@ extern "C" int jpg_chain_pass_finish(jpg_ctx *c, uint64_t *nbits, size_t *piece_
     uint64_t whole = 0;
     if (ch.rank == 0) {
         const uint64_t tag = 0x8000u | (uint32_t)((ch.taken - 1) & 0x7fff);
-        const uint64_t *word = &ch.mail_host[par * CHAIN_MAX_RANKS + ch.last_of[par]].total;
+        const uint64_t *word = &ch.mail_host[((ch.taken - 1) % CHAIN_SLOTS) * CHAIN_MAX_RANKS + ch.last_of[par]].total;
         const auto t0 = std::chrono::steady_clock::now();
         uint64_t w = 0;
         for (;;) {
@@ -1153,7 +1170,7 @@ extern "C" int jpg_chain_pass_finish(jpg_ctx *c, uint64_t *nbits, size_t *piece_
     if (nbits) *nbits = sl.nbits;
     if (piece_len) *piece_len = sl.scan_len;
     if (bit_offset) *bit_offset = hp.bit_offset;
-    if (byte_offset) *byte_offset = (size_t)hp.byte_offset;
+    if (byte_offset) *byte_offset = (size_t)par * (ch.gather_cap / 2) + (size_t)hp.byte_offset;
     if (total) *total = (size_t)whole;
     return JPG_OK;
 }

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64) void k_chain_place(ChainPass c) {
     __shared__ uint64_t sBits[CHAIN_MAX_RANKS];
     __shared__ uint32_t sTail[CHAIN_MAX_RANKS];
     const int lane = threadIdx.x;
-    const ChainMail *box = c.mail + c.parity * CHAIN_MAX_RANKS;
+    const ChainMail *box = c.mail + c.slot * CHAIN_MAX_RANKS;
     const bool need = lane < c.rank && ((c.active >> lane) & 1);
     bool timeout = false;
     sBits[lane] = mail_wait(&box[lane].bits, need, c.tag, c.timeout_ticks, timeout);
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void k_chain_place(ChainPass c) {
 __global__ __launch_bounds__(64) void k_chain_offset(ChainPass c, unsigned long long gather_cap) {
     __shared__ uint64_t sLen[CHAIN_MAX_RANKS];
     const int lane = threadIdx.x;
-    ChainMail *box = c.mail + c.parity * CHAIN_MAX_RANKS;
+    ChainMail *box = c.mail + c.slot * CHAIN_MAX_RANKS;
     const uint64_t own = c.status->scan_bytes;
     if (lane == 0) mail_store(&box[c.rank].len, mail_pack(c.tag, own));
     const bool need = lane < c.rank && ((c.active >> lane) & 1);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_chain_copy(const ChainParams *params, c
 __global__ __launch_bounds__(64) void k_chain_done(ChainPass c, int collect) {
     __shared__ uint64_t sDone[CHAIN_MAX_RANKS];
     const int lane = threadIdx.x;
-    ChainMail *box = c.mail + c.parity * CHAIN_MAX_RANKS;
+    ChainMail *box = c.mail + c.slot * CHAIN_MAX_RANKS;
     const uint64_t own = (c.params->failed ? DONE_ERROR : 0) | c.params->len;
     if (lane == 0) mail_store(&box[c.rank].done, mail_pack(c.tag, own));
     if (!collect) return;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void k_chain_done(ChainPass c, int collect) {
 
 bool pass_ok(const ChainPass &c) {
     return c.mail && c.params && c.status && c.rank >= 0 && c.rank < CHAIN_MAX_RANKS && c.pred_rank < c.rank &&
-           (c.parity == 0 || c.parity == 1) && (c.tag & 0x8000u) && c.tag <= 0xffffu;
+           c.slot >= 0 && c.slot < CHAIN_SLOTS && (c.tag & 0x8000u) && c.tag <= 0xffffu;
 }
 
 }  // namespace

@@ -45,7 +45,7 @@ __device__ __forceinline__ void chain_fail(const ChainPass &c) {
 // First step of a pass, called by one wave: clears params->failed, publishes this stripe's last DC coefficients
 // (dc3, LDS or registers of the caller) and waits for the predecessor's -> params->pred.
 __device__ __forceinline__ void chain_exchange_dc(const ChainPass &c, const int16_t *dc3, int lane) {
-    ChainMail *box = c.mail + c.parity * CHAIN_MAX_RANKS;
+    ChainMail *box = c.mail + c.slot * CHAIN_MAX_RANKS;
     if (lane == 0) {
         c.params->failed = 0;
         const uint64_t v = ((uint64_t)(uint16_t)dc3[0] << 32) | ((uint64_t)(uint16_t)dc3[1] << 16) | (uint16_t)dc3[2];

@@ -222,7 +222,8 @@ std::vector<uint8_t> encode_striped(const Args &args, const jph_bmp &bmp, int v,
     // page-locked host memory.  Anything it refuses (JPG_ERR_STATE: narrow image; JPG_ERR_CHAIN: scan larger than
     // the buffer) falls through to the steps below.
     if (n <= 64 && !active.empty() && active[0] == 0) {
-        const size_t cap = (size_t)bmp.width * (size_t)bmp.height / 2 + (1u << 20);
+        // (the buffer has two halves, one per pass in flight; the one pass here fills the first)
+        const size_t cap = 2 * ((size_t)bmp.width * (size_t)bmp.height / 2 + (1u << 20));
         void *mailbox = jpg_chain_mailbox_alloc();
         bool peers = true;
         for (int k : active) peers = peers && jpg_peer_access(args.devices[k % args.devices.size()], owner) == 1;

@@ -63,9 +63,14 @@ struct DevStatus {
 // where a piece lies) through a mailbox in page-locked host memory that every GPU of the node reads and writes
 // directly: no host thread takes part between the first and the last kernel of a pass.
 constexpr int CHAIN_MAX_RANKS = 64;
-// One record per (parity of the pass number, rank), written only by kernels of that rank.  Every word is
+// Passes whose records exist side by side.  A rank publishes its DC values before it waits for anything, so with two
+// passes of every rank in flight a fast rank may publish for pass f + 3 while the slowest still reads the values of
+// pass f + 1 (rank 0 queues pass q only after the whole of pass q - 2 is in place, and no rank completes a pass rank 0
+// has not begun): three passes must not share a record, four do not.
+constexpr int CHAIN_SLOTS = 4;
+// One record per (pass number mod CHAIN_SLOTS, rank), written only by kernels of that rank.  Every word is
 // {tag:16 | value:48} and stored whole; tag = 0x8000 | (pass & 0x7fff), so a zeroed mailbox and the words of
-// two passes ago (same parity) never look valid.
+// an earlier pass in the same record never look valid.
 struct ChainMail {
     uint64_t dc;     // value = y:16 | cb:16 | cr:16, the DC coefficients of the stripe's last Y, Cb, Cr blocks
     uint64_t bits;   // bits of the stripe's unstuffed stream
@@ -76,7 +81,7 @@ struct ChainMail {
     uint64_t pad[2];
 };
 static_assert(sizeof(ChainMail) == 64, "one record per 64 bytes");
-constexpr size_t CHAIN_MAILBOX_BYTES = 2 * CHAIN_MAX_RANKS * sizeof(ChainMail);
+constexpr size_t CHAIN_MAILBOX_BYTES = CHAIN_SLOTS * CHAIN_MAX_RANKS * sizeof(ChainMail);
 // What the gate kernels of a context leave for the kernels queued behind them (device memory of the context).
 struct ChainParams {
     int16_t pred[4];        // DC predictors the stripe starts from
@@ -124,12 +129,12 @@ struct EntropyBufs {
 
 // One pass of a stripe through the chain, as the launchers below need it
 struct ChainPass {
-    ChainMail *mail;            // [2][CHAIN_MAX_RANKS], host memory visible to every GPU
+    ChainMail *mail;            // [CHAIN_SLOTS][CHAIN_MAX_RANKS], host memory visible to every GPU
     ChainParams *params;        // this context's
     DevStatus *status;          // this context's status record of the pass (errors are raised here)
     uint32_t err_epoch;         // ... tagged with this
     uint32_t tag;               // 0x8000 | (pass & 0x7fff)
-    int parity;                 // pass & 1
+    int slot;                   // pass % CHAIN_SLOTS
     int rank;
     int pred_rank;              // last rank before this one with a stripe of its own, -1: none
     uint64_t active;            // bit k: rank k has a stripe

@@ -333,7 +333,9 @@ class StripeChain:
         from . import _native as N
         self.N, self.L, self.enc, self.ex = N, N.lib(), encoder, exchange
         self.rank, self.world, self.device = exchange.rank, exchange.world, encoder.device
-        self.cap = max(int(gather_cap), 1)
+        # two passes may be in flight: each has its own half of the buffer (gather_cap bytes for one scan)
+        self.cap = 2 * ((max(int(gather_cap), 1) + 255) & ~255)
+        self.offset = 0                   # rank 0: where the scan of the pass finish() took last begins
         self._mine = []                   # rank 0: (address, free function) of what it allocated
         self._opened = []                 # other ranks: addresses opened through handles
         self.mailbox = self._share(self.L.jpg_chain_mailbox_alloc, self.L.jpg_free, required=True)
@@ -379,8 +381,9 @@ class StripeChain:
 
     def encode_async(self, width, height, stride, v, stripe_ptr=None, rows=None, bottom_up=True):
         """Queues one pass: this rank's stripe (device rows at stripe_ptr, or sliced out of the host array `rows` of the
-        whole image) through the chain.  Up to two passes may be queued before finish() takes the first.  True when
-        this rank has a stripe (only then is there something to finish)."""
+        whole image) through the chain.  Up to two passes may be queued before finish() takes the first; rank 0 has
+        read (or given up) the scan of the pass before the last one by then, whose half of the buffer the new pass
+        fills.  True when this rank has a stripe (only then is there something to finish)."""
         plan = plan_stripes(height, v, self.world)
         mask = sum(1 << k for k, (a, b) in enumerate(plan) if b > a)
         y0, y1 = plan[self.rank]
@@ -396,8 +399,11 @@ class StripeChain:
     def finish(self):
         """Waits for the oldest queued pass.  The length of the whole scan on rank 0 -- whose pass ends when every
         piece lies in the gather buffer -- and None elsewhere."""
-        total = self.enc.chain_pass_finish()[4]
-        return total if self.rank == 0 else None
+        res = self.enc.chain_pass_finish()
+        if self.rank != 0:
+            return None
+        self.offset = res[3]              # (rank 0's piece is the first of the scan)
+        return res[4]
 
     def encode(self, width, height, stride, v, stripe_ptr=None, rows=None, bottom_up=True):
         """One pass, queued and waited for."""
@@ -406,13 +412,13 @@ class StripeChain:
         return self.finish()
 
     def read(self, n):
-        """Rank 0: the first n bytes of the gather buffer."""
+        """Rank 0: the first n bytes of the scan of the pass finish() took last."""
         import ctypes as C
         out = np.zeros(n, np.uint8)
         if n and self.gather == "device":
-            self.N.check(None, self.L.jpg_device_to_host(self.device, out.ctypes.data, self.buffer, n))
+            self.N.check(None, self.L.jpg_device_to_host(self.device, out.ctypes.data, self.buffer + self.offset, n))
         elif n:
-            C.memmove(out.ctypes.data, self.buffer, n)
+            C.memmove(out.ctypes.data, self.buffer + self.offset, n)
         return out
 
     def close(self):

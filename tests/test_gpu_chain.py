@@ -8,53 +8,73 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _chain_encode(J, rows, w, h, ratio, algo, n, passes=1, gather_host=False, cap=None):
+def _chain_encode_all(J, images, w, h, ratio, algo, n, gather_host=False, cap=None, in_flight=2):
+    """images: one array of rows per pass.  Up to `in_flight` passes are queued on every context before the oldest is
+    waited for; returns the scan of every pass, read out of its half of the gather buffer."""
     S = J.stripes
     L = J._native.lib()
     _, v = J.get_downsampling_factor(ratio)
-    stride = rows.shape[1]
+    stride = images[0].shape[1]
     plan = S.plan_stripes(h, v, n)
     active = [k for k, (a, b) in enumerate(plan) if b > a]
     mask = sum(1 << k for k in active)
     mailbox = L.jpg_chain_mailbox_alloc()
     assert mailbox
-    cap = cap or (w * h // 2 + (1 << 20))
+    cap = cap or 2 * (w * h // 2 + (1 << 20))              # two halves, one per pass in flight
     gather = L.jpg_host_alloc(cap) if gather_host else L.jpg_device_alloc(0, cap)
     assert gather
     import torch
-    encs, devs = {}, {}
+    encs = {}
     for k in active:
         encs[k] = J.Encoder(ratio, algo)
         encs[k].chain_setup(k, n, mailbox, gather, cap)
-        sub = np.ascontiguousarray(S.stripe_rows(rows, h, plan[k][0], plan[k][1], True))
-        devs[k] = torch.from_numpy(sub).cuda()
+    devs = [{k: torch.from_numpy(np.ascontiguousarray(S.stripe_rows(rows, h, plan[k][0], plan[k][1], True))).cuda()
+             for k in active} for rows in images]
     torch.cuda.synchronize()
-    out = None
-    for p in range(passes):
-        for k in active:                                  # ascending ranks: a gate only waits for lower ranks
-            encs[k].stripe_device(devs[k].data_ptr(), w, plan[k][1] - plan[k][0], stride, True)
-            encs[k].chain_pass_async(mask)
+    outs = []
+
+    def take(p):
         res = {k: encs[k].chain_pass_finish() for k in reversed(active)}
-        total = res[active[0]][4] if active[0] == 0 else None
+        total = res[0][4]
         assert total == sum(r[1] for r in res.values())
-        bit = byte = 0
+        base = (p & 1) * (cap // 2)
+        bit, byte = 0, base
         for k in active:
             assert res[k][2] == bit and res[k][3] == byte, (k, res[k], bit, byte)
             bit += res[k][0]
             byte += res[k][1]
         out = np.zeros(total, np.uint8)
         if gather_host:
-            C.memmove(out.ctypes.data, gather, total)
+            C.memmove(out.ctypes.data, gather + base, total)
         else:
-            J._native.check(None, L.jpg_device_to_host(0, out.ctypes.data, gather, total))
-    for e in encs.values():
-        e.close()
-    if gather_host:
-        L.jpg_free(gather)
-    else:
-        L.jpg_device_free(0, gather)
-    L.jpg_free(mailbox)
-    return out
+            J._native.check(None, L.jpg_device_to_host(0, out.ctypes.data, gather + base, total))
+        outs.append(out)
+
+    try:
+        for p in range(len(images)):
+            if p >= in_flight:
+                take(p - in_flight)
+            for k in active:                                  # ascending ranks: a gate only waits for lower ranks
+                encs[k].stripe_device(devs[p][k].data_ptr(), w, plan[k][1] - plan[k][0], stride, True)
+                encs[k].chain_pass_async(mask)
+        for p in range(max(0, len(images) - in_flight), len(images)):
+            take(p)
+    finally:
+        for e in encs.values():
+            e.close()
+        if gather_host:
+            L.jpg_free(gather)
+        else:
+            L.jpg_device_free(0, gather)
+        L.jpg_free(mailbox)
+    return outs
+
+
+def _chain_encode(J, rows, w, h, ratio, algo, n, passes=1, gather_host=False, cap=None):
+    outs = _chain_encode_all(J, [rows] * passes, w, h, ratio, algo, n, gather_host, cap, in_flight=1)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o, outs[0])
+    return outs[0]
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 8])
@@ -74,9 +94,23 @@ def test_chain_more_ranks_than_mcu_rows_and_host_gather(J, oracle):
     np.testing.assert_array_equal(_chain_encode(J, rows, w, h, ratio, "bin-dct", 5, passes=2, gather_host=True), want)
 
 
+@pytest.mark.parametrize("n,gather_host", [(1, False), (4, False), (8, True)])
+def test_chain_two_passes_in_flight_of_different_images(J, oracle, n, gather_host):
+    """Seven passes over images of different content (so of different lengths and offsets), two of them queued at
+    any time: the hand-over records, the halves of the gather buffer and the contexts' two sets of buffers are all
+    reused while the pass before is still running."""
+    w, h, ratio = 1544, 136, (4, 2, 0)
+    images = [J.host.synth_bgr(w, h, seed=700 + i, noise_only=(i % 3 == 1)) for i in range(7)]
+    want = [oracle.RefImage.from_bgr(r, w, h, r.shape[1], ratio, oracle.BIN).encode().stuffed_scan() for r in images]
+    got = _chain_encode_all(J, images, w, h, ratio, "bin-dct", n, gather_host=gather_host)
+    assert len({x.size for x in want}) > 3
+    for p, (g, x) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(g, x, err_msg="pass %d" % p)
+
+
 def test_chain_gather_too_small_is_an_error_not_a_fault(J):
     w, h, ratio = 1024, 256, (4, 2, 0)
     rows = J.host.synth_bgr(w, h, seed=6, noise_only=True)
     with pytest.raises(J._native.JpgError) as e:
-        _chain_encode(J, rows, w, h, ratio, "bin-dct", 2, cap=4096)
+        _chain_encode(J, rows, w, h, ratio, "bin-dct", 2, cap=8192)
     assert e.value.code == -13

@@ -42,7 +42,7 @@ def chain_scan(rows, w, h, stride, ratio, algo, vs, bottom_up, n):
     plan = S.plan_stripes(h, vs, n)
     active = [k for k, (a, b) in enumerate(plan) if b > a]
     mask = sum(1 << k for k in active)
-    cap = max(1 << 16, w * h * 4)
+    cap = 2 * max(1 << 16, w * h * 4)                        # two halves: one per pass in flight
     mailbox, gather = L.jpg_chain_mailbox_alloc(), L.jpg_device_alloc(0, cap)
     es, dev = {}, {}
     for k in active:

@@ -22,7 +22,7 @@ torch.cuda.synchronize()
 S, L = J.stripes, J._native.lib()
 plan = S.plan_stripes(h, 2, n)
 mask = (1 << n) - 1
-cap = w * h // 2
+cap = 2 * (w * h // 2)                        # two halves: one per pass in flight
 mailbox, gather = L.jpg_chain_mailbox_alloc(), L.jpg_device_alloc(0, cap)
 encs = [J.Encoder(ratio, "real-dct") for _ in range(n)]
 for k, e in enumerate(encs):
