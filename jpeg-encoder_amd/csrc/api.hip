@@ -46,7 +46,7 @@ struct jpg_ctx {
     struct Slot {
         EntropyBufs eb{};
         const uint8_t **d_srcs = nullptr; size_t cap_srcs = 0;   // device array of a batch's pixel pointers
-        size_t cap_clen = 0, cap_sparse = 0, cap_scan = 0, cap_status = 0, cap_sagg = 0, cap_sgrp = 0, cap_shyp = 0;
+        size_t cap_clen = 0, cap_sparse = 0, cap_scan = 0, cap_status = 0, cap_sagg = 0, cap_sgrp = 0, cap_shyp = 0, cap_gsum = 0;
         DevStatus *h_status = nullptr;  // [cap_status] pinned copy of eb.status
         DevStatus *h_status_alt = nullptr;   // not owned: where the kernels of the launches being queued put the copy instead
         hipEvent_t e_done = nullptr;    // entropy kernel finished (recorded on stream)
@@ -263,7 +263,7 @@ extern "C" void jpg_destroy(jpg_ctx *c) {
     for (void *p : dev)
         if (p) (void)hipFree(p);
     for (jpg_ctx::Slot &sl : c->slot) {
-        void *sdev[] = {sl.d_srcs, sl.eb.clen, sl.eb.sparse, sl.eb.status, sl.eb.bits, sl.eb.sagg, sl.eb.sgrp, sl.eb.shyp,
+        void *sdev[] = {sl.d_srcs, sl.eb.clen, sl.eb.sparse, sl.eb.status, sl.eb.bits, sl.eb.gsum, sl.eb.sagg, sl.eb.sgrp, sl.eb.shyp,
                         sl.eb.sticket, sl.eb.scan, sl.eb.trace};
         for (void *p : sdev)
             if (p) (void)hipFree(p);
@@ -375,6 +375,7 @@ static int ensure_entropy(jpg_ctx *c, bool coded) {
     sl.nblocks = nblk;
     int e;
     if ((e = grow(c, sl.eb.clen, sl.cap_clen, nimg * cstride))) return e;
+    if ((e = grow(c, sl.eb.gsum, sl.cap_gsum, nimg * (cstride / 64)))) return e;
     if ((e = grow(c, sl.eb.sparse, sl.cap_sparse, nimg * cstride * slot_words))) return e;
     if ((e = grow(c, sl.eb.scan, sl.cap_scan, nimg * scan_stride))) return e;
     sl.eb.scan_stride = scan_stride;
@@ -390,8 +391,8 @@ static int ensure_entropy(jpg_ctx *c, bool coded) {
         sl.cap_status = nimg;
         sl.eb.epoch = 0;
     }
-    if (2 * nimg > sl.cap_ticket) {
-        if ((e = grow(c, sl.eb.sticket, sl.cap_ticket, 2 * nimg))) return e;
+    if (std::max<size_t>(2 * nimg, TICKET_WORDS_SINGLE) > sl.cap_ticket) {
+        if ((e = grow(c, sl.eb.sticket, sl.cap_ticket, std::max<size_t>(2 * nimg, TICKET_WORDS_SINGLE)))) return e;
         HIP_TRY(c, hipMemset(sl.eb.sticket, 0, sl.cap_ticket * sizeof(uint32_t)));   // the kernel leaves them at 0
     }
     // the hand-off words are laid out per image with the stride nseg: a change of either relocates them
@@ -1325,14 +1326,36 @@ static void print_trace(const jpg_ctx::Slot &sl) {
     if (!sl.eb.trace || !getenv("JPG_TRACE_PRINT")) return;
     static unsigned long long h[4096 * 8];
     (void)hipMemcpy(h, sl.eb.trace, sizeof h, hipMemcpyDeviceToHost);
-    unsigned long long t0 = ~0ull;
-    for (int b = 0; b < 512; b++)
-        if (h[b * 8] && h[b * 8] < t0) t0 = h[b * 8];
-    for (int b : {0, 1, 100, 200, 300, 395, 400, 511}) {
-        fprintf(stderr, "wg %3d:", b);
-        for (int k = 0; k < 8; k++) fprintf(stderr, " %6.2f", h[b * 8 + k] ? (double)(h[b * 8 + k] - t0) / 100.0 : -1.0);
-        fprintf(stderr, " us\n");
+    double sum[8] = {0}, life_max = 0;
+    int n = 0;
+    for (int b = 0; b < 4096; b++) {
+        double life = 0;
+        for (int k = 0; k < 8; k++) life += (double)h[b * 8 + k];
+        if (life == 0) continue;
+        n++;
+        for (int k = 0; k < 8; k++) sum[k] += (double)h[b * 8 + k];
+        life_max = life > life_max ? life : life_max;
     }
+    fprintf(stderr, "stuffing kernel, %d workgroups, us per workgroup in phases 0..7:", n);
+    double all = 0;
+    for (int k = 0; k < 8; k++) { fprintf(stderr, " %7.2f", sum[k] / (n ? n : 1) / 100.0); all += sum[k]; }
+    fprintf(stderr, "  life %7.2f (max %7.2f)\n", all / (n ? n : 1) / 100.0, life_max / 100.0);
+    // the workgroups that spent the longest outside the wait for other workgroups (phase 6)
+    for (int top = 0; top < 3; top++) {
+        int best = -1;
+        double best_busy = -1;
+        for (int b = 0; b < 4096; b++) {
+            double busy = 0;
+            for (int k = 0; k < 8; k++) busy += k == 6 ? 0 : (double)h[b * 8 + k];
+            if (busy > best_busy) { best_busy = busy; best = b; }
+        }
+        if (best < 0 || best_busy <= 0) break;
+        fprintf(stderr, "  busiest workgroup %4d:", best);
+        for (int k = 0; k < 8; k++) fprintf(stderr, " %7.2f", (double)h[best * 8 + k] / 100.0);
+        fprintf(stderr, "\n");
+        for (int k = 0; k < 8; k++) h[best * 8 + k] = 0;
+    }
+    (void)hipMemset(sl.eb.trace, 0, sizeof h);
 }
 #endif
 

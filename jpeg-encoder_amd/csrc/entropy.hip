@@ -60,18 +60,20 @@ __device__ __forceinline__ uint64_t hw_value(uint64_t w) { return w & ((1ull << 
 __device__ __forceinline__ void hw_store(uint64_t *p, uint64_t w) {
     __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void hw_store_plain(uint64_t *p, uint64_t w) { hw_store(p, w); }
 __device__ __forceinline__ uint64_t hw_load(const uint64_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Three levels of running sums over items 0..n-1 (chunks of blocks here, segments
-// of bytes in the stuffing kernel), each word {epoch | valid | value}:
+// Three levels of running sums over items 0..n-1 (the segments of bytes of the stuffing kernel), each word
+// {epoch | valid | value}:
 //   agg[i]  value of item i                (published by i as soon as it is known)
 //   grp[g]  sum of items 64g..64g+63       (published by the last item of the group)
 //   hyp[h]  sum of groups 64h..64h+63      (published by the last item of the hyper-group)
-// prefix(i) = sum hyp[< h] + sum grp[64h .. g-1] + sum agg[64g .. i-1].  Every sum is
-// published as soon as it is known and before its publisher waits for anything else, so
-// the publications never form a chain; an item only waits for items with a lower number.
+// prefix(i) = sum hyp[< h] + sum grp[64h .. g-1] + sum agg[64g .. i-1].  An item publishes its value, and the last
+// item of a group the sums it closes, in the first half of its work (sums_close), where it only waits for the
+// values of items before it; the prefix is taken in the second half (sums_prefix), a turn later, and publishes
+// nothing: no item ever waits for the second half of another.
 struct Sums {
     uint64_t *agg, *grp, *hyp;
     uint32_t epoch;
@@ -98,7 +100,9 @@ __device__ __forceinline__ uint64_t hw_wait(const uint64_t *p, bool need, uint64
     for (uint32_t spin = 0;; spin++) {
         if (__ballot(!ok) == 0) break;
         if (spin >= SPIN_LIMIT) { timeout = true; break; }
-        if (spin) __builtin_amdgcn_s_sleep(1);
+        // (polls that go on back off to one a microsecond: a thousand workgroups polling flat out slow down the
+        // very stores they wait for)
+        for (uint32_t k = 0; k < (spin < 8u ? spin : 8u); k++) __builtin_amdgcn_s_sleep(4);
         if (!ok) {
             w = hw_load(p);
             ok = hw_valid(w, epoch);
@@ -116,23 +120,39 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
     return v;
 }
 
-// exclusive prefix of item i whose own value is `own`; called by a whole wave
-__device__ __forceinline__ uint64_t sums_prefix(const Sums &s, long long i, uint64_t own, const Probe &pr, int lane,
-                                                bool &timeout) {
+// sum over the wave of values whose sum fits 32 bits, in every lane
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63);
+}
+
+// Item i, whose value `own` has been published, is the last of its group (and perhaps of its hyper-group): the sums
+// it closes.  Called by a whole wave.  VALUE_BITS: an item's value is below 2^VALUE_BITS; 64 items, 64 groups or 64
+// hyper-groups must add up to less than 2^32.
+template <int VALUE_BITS>
+__device__ __forceinline__ void sums_close(const Sums &s, long long i, uint32_t own, int lane, bool &timeout) {
+    static_assert(VALUE_BITS + 6 + 6 + 6 <= 32, "sums of 64 hyper-groups in 32 bits");
     const long long g = i >> 6, h = g >> 6;
-    const bool closes_group = (i & 63) == 63 || i == s.n - 1;
-    const bool closes_hyper = closes_group && ((g & 63) == 63 || i == s.n - 1);
-    const long long ia = (g << 6) + lane;
-    const uint64_t sum_a = wave_sum64(hw_wait(&s.agg[ia], ia < i, pr.wa, s.epoch, timeout));
-    const uint64_t gv = sum_a + own;
-    if (closes_group && lane == 0) hw_store(&s.grp[g], hw_pack(s.epoch, gv));
-    const long long ig = (h << 6) + lane;
-    const uint64_t sum_g = wave_sum64(hw_wait(&s.grp[ig], ig < g, pr.wg, s.epoch, timeout));
-    if (closes_hyper && lane == 0) hw_store(&s.hyp[h], hw_pack(s.epoch, sum_g + gv));
-    uint64_t sh = 0;
+    const bool closes_hyper = (g & 63) == 63;
+    const long long ia = (g << 6) + lane, ig = (h << 6) + lane;
+    const uint64_t wa = ia < i ? hw_load(&s.agg[ia]) : 0;
+    const uint64_t wg = closes_hyper && ig < g ? hw_load(&s.grp[ig]) : 0;
+    const uint32_t gv = wave_sum32((uint32_t)hw_wait(&s.agg[ia], ia < i, wa, s.epoch, timeout)) + own;
+    if (lane == 0) hw_store(&s.grp[g], hw_pack(s.epoch, gv));
+    if (!closes_hyper) return;
+    const uint32_t sum_g = wave_sum32((uint32_t)hw_wait(&s.grp[ig], ig < g, wg, s.epoch, timeout));
+    if (lane == 0) hw_store(&s.hyp[h], hw_pack(s.epoch, (uint64_t)sum_g + gv));
+}
+
+// exclusive prefix of item i; called by a whole wave
+__device__ __forceinline__ uint64_t sums_prefix(const Sums &s, long long i, const Probe &pr, int lane, bool &timeout) {
+    const long long g = i >> 6, h = g >> 6;
+    const long long ia = (g << 6) + lane, ig = (h << 6) + lane;
+    const uint32_t va = (uint32_t)hw_wait(&s.agg[ia], ia < i, pr.wa, s.epoch, timeout);
+    const uint32_t vg = (uint32_t)hw_wait(&s.grp[ig], ig < g, pr.wg, s.epoch, timeout);
+    uint64_t sh = 0;   // (up to 2^30 per hyper-group)
     for (long long j0 = 0; j0 < h; j0 += 64)
-        sh += hw_wait(&s.hyp[j0 + lane], j0 + lane < h, j0 ? 0 : pr.wh, s.epoch, timeout);
-    return wave_sum64(sh) + sum_g + sum_a;
+        sh += wave_sum32((uint32_t)hw_wait(&s.hyp[j0 + lane], j0 + lane < h, j0 ? 0 : pr.wh, s.epoch, timeout));
+    return sh + wave_sum32(va + vg);
 }
 
 __device__ __forceinline__ uint32_t mod_small(uint32_t x, uint32_t nb, uint32_t magic) {   // x < 1024
@@ -302,6 +322,8 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
 struct StreamArgs {
     const uint32_t *sparse;  // chunk slots written by k_entropy
     const uint32_t *clen;    // bits per chunk
+    const uint32_t *gsum;    // bits per group of 64 chunks (k_group_sums)
+    size_t gsum_stride;      // groups per image in gsum
     long long nchunks;       // per image
     int ngroups;             // groups of 64 chunks of an image (<= MAX_GROUPS)
     // a batch: image i is handled by workgroups i * wpi .. (i + 1) * wpi - 1 and owns a stride of each array
@@ -358,33 +380,51 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 #ifdef JPG_TRACE
-// debug build: wall-clock stamps (100 MHz) of the phases of the first pass of every workgroup (single images)
-// (kept in registers and stored at the end of the first pass, so that the stores do not perturb the phases)
-#define JPG_STAMP(K) do { stamps[K] = wall_clock64(); if ((K) == 7 && threadIdx.x == 0 && a.trace && !stamped) { \
-        for (int k_ = 0; k_ < 8; k_++) a.trace[blockIdx.x * 8 + k_] = stamps[k_]; stamped = true; } } while (0)
+// debug build: wall-clock time (100 MHz) a workgroup spends in each phase, summed over its segments: phase K runs
+// from the stamp before it to JPG_STAMP(K) (single images; stored when the workgroup leaves)
+#define JPG_STAMP(K) do { const unsigned long long now_ = wall_clock64(); stamps[K] += now_ - last_stamp; last_stamp = now_; } while (0)
 #else
 #define JPG_STAMP(K) do { } while (0)
 #endif
+
+// bits of every group of 64 chunks of every image (blockIdx.y): a wave per group
+__global__ __launch_bounds__(1024) void k_group_sums(const uint32_t *__restrict__ clen, long long nchunks, long long cstride,
+                                                     int ngroups, uint32_t *__restrict__ gsum, size_t gstride) {
+    const int lane = threadIdx.x & 63, g = blockIdx.x * 16 + (threadIdx.x >> 6);
+    if (g >= ngroups) return;
+    const long long c = (long long)g * 64 + lane;
+    const uint32_t v = c < nchunks ? clen[blockIdx.y * cstride + c] : 0u;
+    const uint32_t sum = wave_incl_scan(v);
+    if (lane == 63) gsum[blockIdx.y * gstride + g] = sum;
+}
 
 // Threads per segment: 512 for a single image, whose stuffing nothing else hides (the kernel is a chain of short
 // dependent steps, and more waves keep the per-thread instruction count of every step small); 256 for a batch,
 // which is stuffed beside the coding kernel of the next batch: one wave per SIMD, 64 registers and under 8 KiB of
 // LDS fit into what four workgroups of the coding kernel leave free on a CU.
 constexpr int ST_THREADS_SINGLE = 512, ST_THREADS_BATCH = 256;
+// teams of workgroups that share a ticket counter (words of an image's counters: [0] the image's counter, [1] workgroups
+// that have left, from TEAM_BASE on a record of TEAM_WORDS per team)
+constexpr int TEAM = 32, TEAM_RING = 8, TEAM_WORDS = 64, TEAM_BASE = 64, MAX_TEAMS = (TICKET_WORDS_SINGLE - TEAM_BASE) / TEAM_WORDS;
+#ifndef JPG_ST_DEPTH
+#define JPG_ST_DEPTH 1
+#endif
+constexpr int ST_DEPTH_SINGLE = JPG_ST_DEPTH;
 
 // STUFF: byte stuffing of the (shifted) stream into a.out, a workgroup per segment of
 // STUFF_SEG stream bytes (blockIdx.x, + gridDim.x, ...).  !STUFF: the stream itself, dense.
 // Dynamic LDS: (ngroups + 1) 64-bit prefix sums of the chunk lengths per group.
 // The kernel is a chain of short dependent steps.  Four waves per workgroup: one per SIMD, which is what fits
 // beside the workgroups of the coding kernel of the next batch (see launch_stream).
-template <bool STUFF, int ST_THREADS>
+// DEPTH: fronts of later segments between a segment's front and its back (see the three steps below).
+template <bool STUFF, int ST_THREADS, int DEPTH, bool TEAMS>
 // (at most 64 registers: eight waves per SIMD when it has the device to itself)
 __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_stream(StreamArgs a) {
     constexpr int ST_WAVES = ST_THREADS / 64;
     constexpr int WPT = SEG_WORDS / ST_THREADS;   // 32-bit words of the segment per thread
-    constexpr int DIRECT_ITEMS = ST_THREADS;      // segments whose predecessors' counts are read directly, one per thread
     constexpr int GATHER_ROUNDS = (DENSE_WORDS + 2 * 132 + ST_THREADS - 1) / ST_THREADS;
     static_assert(SEG_WORDS == WPT * ST_THREADS && ST_THREADS >= TABLE, "whole words per thread");
+    static_assert(STUFF_SEG <= (1 << 13) && MAX_GROUPS <= 64 * 64 * 64, "count of a segment; two rounds of 64 probes");
     if (a.chain) {
         a.shift = a.chain->shift;
         a.head = a.chain->head;
@@ -393,6 +433,7 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         const int img = blockIdx.x / a.wpi;
         a.sparse += (size_t)img * a.cstride * a.slot_words;
         a.clen += img * a.cstride;
+        a.gsum += img * a.gsum_stride;
         a.out += img * a.out_stride;
         a.agg += img * a.agg_stride;
         a.grp += img * a.grp_stride;
@@ -419,32 +460,13 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     // last wave, which loads nothing else in the first phases of a round (a wave's loads return in order).
     const bool ticketer = tid == ST_THREADS - 1;
     uint32_t ticket = 0;
-    if (STUFF && ticketer) ticket = atomicAdd(&a.ticket[0], 1u);
 #ifdef JPG_TRACE
     unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool stamped = false;
+    unsigned long long last_stamp = wall_clock64();
 #endif
 
-    // ---- bits per group, then their running sums
-    for (int g = tid; g < a.ngroups; g += ST_THREADS) {
-        const long long c0 = (long long)g * 64;
-        uint32_t sum = 0;
-        if (c0 + 64 <= a.nchunks) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(a.clen + c0);
-            uint4 v[8];                                          // two batches: the kernel has to stay within 64 registers
-#pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = p[k];
-#pragma unroll
-            for (int k = 0; k < 8; k++) sum += v[k].x + v[k].y + v[k].z + v[k].w;
-#pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = p[8 + k];
-#pragma unroll
-            for (int k = 0; k < 8; k++) sum += v[k].x + v[k].y + v[k].z + v[k].w;
-        } else {
-            for (long long c = c0; c < a.nchunks; c++) sum += a.clen[c];
-        }
-        sG[g] = sum;
-    }
+    // ---- bits per group (summed up by k_group_sums, queued before this kernel), then their running sums
+    for (int g = tid; g < a.ngroups; g += ST_THREADS) sG[g] = a.gsum[g];
     lds_barrier();
     JPG_STAMP(0);
     const int per = (a.ngroups + ST_THREADS - 1) / ST_THREADS;
@@ -470,7 +492,7 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     }
     if (tid == 0) sG[a.ngroups] = nbits;
     lds_barrier();
-    JPG_STAMP(1);
+    JPG_STAMP(0);
 
     const uint64_t tbits = nbits + a.shift;
     const uint64_t nbytes = (STUFF && !a.is_last) ? tbits >> 3 : (tbits + 7) >> 3;
@@ -478,28 +500,83 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const uint64_t nloop = nseg ? nseg : 1;          // the tail of an empty stripe still has to be reported
     const Sums sums{a.agg, a.grp, a.hyp, a.epoch, (long long)nseg};
 
-    uint64_t seg = wg;
-    if (STUFF) {
-        if (ticketer) sSeg = ticket;
-        lds_barrier();
-        seg = sSeg;
-    }
-    while (seg < nloop) {
-        if (STUFF && ticketer) ticket = atomicAdd(&a.ticket[0], 1u);   // used at the end of this round
-        // ---- offsets of the chunks under this segment (first TABLE threads)
+    // A segment goes through three steps, and a workgroup works on three segments at a time, a step of each in
+    // turn, so that every wait for memory or for another workgroup has a step of another segment to hide behind:
+    //   ahead: the group of chunks its first bit lies in is looked up, the lengths of the chunks from there on asked for
+    //   front: the segment's bits are put in place (sD) and counted, the count published; waits for no other workgroup
+    //   back:  the 0xFF bytes of all segments before it (asked for in the middle of the next segment's front,
+    //          by which time they have mostly been published), then its bytes, stuffed, to their place
+    struct Ahead {
+        int g0;              // group of 64 chunks the segment's first bit lies in
+        uint32_t v;          // this thread's chunk length from the start of that group on (first TABLE threads)
+    };
+    struct Held {
+        uint32_t t[WPT];     // the thread's words of the segment
+        uint32_t before_in_seg, total;   // 0xFF bytes: in the words of the threads before, in the segment
+        uint64_t seg;
+        bool valid;
+    };
+
+    // Tickets.  All workgroups of a device drawing from one counter get a number every 12 to 15 ns between them:
+    // less than the 4 KiB segments of one large stream need.  TEAMS (single images): the workgroups draw in teams
+    // of TEAM from a counter of their team; the first of every TEAM draws of a team (the leader of that round)
+    // draws a window of TEAM consecutive segments from the counter of the image and publishes it in the team's
+    // record for the other TEAM - 1, who find their segment in it by the number they drew.  Windows are handed
+    // to teams, and their segments to workgroups, in the order of the draws, by workgroups that are running:
+    // every segment below one that is held is held too, or is the next its team hands out.
+    uint32_t *const team_rec = a.ticket + TEAM_BASE + (wg / TEAM) * TEAM_WORDS;      // [0] the team's counter
+    uint64_t *const team_win = reinterpret_cast<uint64_t *>(team_rec + 32);          // [TEAM_RING] {round + 1 : 32 | window : 32}
+    uint32_t window = 0;
+    int drawing = 0;                     // ticketer: 1 drawn from the team, 2 leader has drawn a window, 3 and published it
+    auto draw_begin = [&]() {
+        if (!ticketer) return;
+        ticket = atomicAdd(TEAMS ? team_rec : &a.ticket[0], 1u);
+        drawing = 1;
+    };
+    auto draw_window = [&]() {           // (waits for the team's number)
+        if (!TEAMS || !ticketer || drawing != 1) return;
+        if ((ticket & (TEAM - 1)) == 0) window = atomicAdd(&a.ticket[0], 1u);
+        drawing = 2;
+    };
+    auto draw_publish = [&]() {          // (waits for the window)
+        if (!TEAMS || !ticketer || drawing != 2) return;
+        if ((ticket & (TEAM - 1)) == 0)
+            hw_store_plain(&team_win[(ticket / TEAM) % TEAM_RING], ((uint64_t)(ticket / TEAM + 1) << 32) | window);
+        drawing = 3;
+    };
+
+    auto ahead = [&](const uint64_t seg) {
         const long long P0 = (long long)seg * SEG_BITS - (long long)a.shift;   // stream position of the segment's first bit
         const uint64_t p0 = P0 > 0 ? (uint64_t)P0 : 0;
-        int g0 = 0;
-        {
-            int l = 0, h = a.ngroups - 1;
-            while (l < h) {
-                const int mid = (l + h + 1) >> 1;
-                if (sG[mid] <= p0) l = mid; else h = mid - 1;
-            }
-            g0 = l;
+        // the last group that starts at or before p0 (sG ascends from 0): two rounds of 64 probes, one per lane
+        const int step = (a.ngroups + 63) >> 6;
+        const int i1 = lane * step;
+        const int c1 = __popcll(__ballot(i1 < a.ngroups && sG[i1] <= p0)) - 1;    // >= 0: sG[0] = 0
+        int l = c1 * step - 1;
+        for (int o = lane; o - lane < step; o += 64) {           // (step <= 64 up to 4096 groups)
+            const int i2 = c1 * step + o;
+            l += __popcll(__ballot(o < step && i2 < a.ngroups && sG[i2] <= p0));
         }
+        const long long cbase = (long long)l * 64;
+        return Ahead{l, (tid < TABLE && cbase + tid < a.nchunks) ? a.clen[cbase + tid] : 0u};
+    };
+
+    // the counts of the segments before `seg`, asked for (not waited for)
+    auto ask = [&](const uint64_t seg) {
+        Probe pr{0, 0, 0};
+        if (nseg && wave == 0) pr = sums_probe(sums, (long long)seg, lane);
+        return pr;
+    };
+
+    // asked: the counts of the segments before ask_seg (whose back follows this front) are asked for half-way, if wanted
+    auto front = [&](const uint64_t seg, const Ahead ah, Held &hd, const bool wanted, const uint64_t ask_seg, Probe &asked) {
+        hd.seg = seg;
+        hd.valid = true;
+        // ---- offsets of the chunks under this segment (first TABLE threads)
+        const long long P0 = (long long)seg * SEG_BITS - (long long)a.shift;
+        const int g0 = ah.g0;
         const long long cbase = (long long)g0 * 64;
-        const uint32_t v = (tid < TABLE && cbase + tid < a.nchunks) ? a.clen[cbase + tid] : 0u;
+        const uint32_t v = ah.v;
         const uint32_t vs = wave_incl_scan(v);
         if (lane == 63) s[wave] = vs;
         lds_barrier();
@@ -537,6 +614,10 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         for (int k = tid; k < DENSE_WORDS; k += ST_THREADS) sD[k] = 0;
         lds_barrier();
         JPG_STAMP(3);
+        // (a wave's loads return in the order they were issued: asked for here, the counts arrive with the words
+        // gathered below and cost no wait of their own)
+        if (STUFF && wanted) asked = ask(ask_seg);
+        if (STUFF) draw_window();
         {
             // thread t takes wanted words t * rounds .. t * rounds + rounds - 1: one search, then a walk
             const int nwant = sW[TABLE];
@@ -566,38 +647,37 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                 }
             }
         }
+        if (STUFF) draw_publish();                               // (the words gathered have arrived, and the window before them)
         lds_barrier();
         JPG_STAMP(4);
 
         // ---- this thread's WPT words
         const uint64_t q = seg * SEG_WORDS + (uint64_t)WPT * tid;  // first word of the stream
-        uint32_t t[WPT];
 #pragma unroll
         for (int k = 0; k < WPT; k++) {
-            t[k] = 0;
+            hd.t[k] = 0;
             if (4 * (q + k) < nbytes) {
-                t[k] = sD[WPT * tid + k];
-                if (q + k == 0 && a.shift) t[k] |= a.head << 24;
+                hd.t[k] = sD[WPT * tid + k];
+                if (q + k == 0 && a.shift) hd.t[k] |= a.head << 24;
                 // a stripe that is not the last one ends at a byte boundary: drop what follows
                 const uint64_t rem = nbytes - 4 * (q + k);
-                if (rem < 4) t[k] &= ~0u << (32 - 8 * (int)rem);
+                if (rem < 4) hd.t[k] &= ~0u << (32 - 8 * (int)rem);
             }
         }
         if (!STUFF) {
 #pragma unroll
             for (int k = 0; k < WPT; k++)
-                if (4 * (q + k) < nbytes) reinterpret_cast<uint32_t *>(a.out)[q + k] = __builtin_bswap32(t[k]);   // padded buffer
+                if (4 * (q + k) < nbytes) reinterpret_cast<uint32_t *>(a.out)[q + k] = __builtin_bswap32(hd.t[k]);   // padded buffer
             if (seg == nloop - 1 && tid == 0) {
                 a.status->nbits = nbits;
                 if (a.host_status) *a.host_status = *a.status;
             }
             lds_barrier();
-            seg += nwg;
-            continue;
+            return;
         }
         uint32_t c = 0;
 #pragma unroll
-        for (int k = 0; k < WPT; k++) c += count_ff(t[k]);
+        for (int k = 0; k < WPT; k++) c += count_ff(hd.t[k]);
         const uint32_t sc = wave_incl_scan(c);
         if (lane == 63) s[wave] = sc;                            // (s[] was last read before the previous barrier)
         lds_barrier();
@@ -609,43 +689,41 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             if (w < wave) before_in_seg += p;
             total += p;
         }
-        // ---- 0xFF bytes in the segments before this one
-        bool timeout = false;
-        if (nseg && seg < DIRECT_ITEMS) {
-            // every thread fetches the count of one earlier segment; the segment's own count is published by
-            // the last wave, which rarely has anything to fetch (loads and stores of a wave complete in
-            // issue order, so a wave that stored first would wait ~2 us for the acknowledgement)
-            if (tid == ST_THREADS - 1) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
-            const bool need = (uint64_t)tid < seg;
-            const uint64_t val = hw_wait(&a.agg[tid], need, need ? hw_load(&a.agg[tid]) : 0, a.epoch, timeout);
-            const uint32_t ws = wave_incl_scan((uint32_t)val);   // a count is at most STUFF_SEG, 1024 of them: 32 bits do
-            if (lane == 63) sPart[wave] = ws;
-            lds_barrier();
-            uint64_t before = 0;
-#pragma unroll
-            for (int w = 0; w < ST_WAVES; w++) before += sPart[w];
-            const int g = (int)(seg >> 6);
-            const bool closes_group = (seg & 63) == 63 || seg == nseg - 1;
-            if (closes_group && tid == 0) hw_store(&a.grp[g], hw_pack(a.epoch, sPart[g] + total));
-            if (seg == nseg - 1 && tid == 0) hw_store(&a.hyp[0], hw_pack(a.epoch, before + total));
-            if (tid == 0) sBefore = before;
-        } else if (wave == 0) {
-            uint64_t before = 0;
-            if (nseg) {
-                if (lane == 0) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
-                const Probe probe = sums_probe(sums, (long long)seg, lane);
-                before = sums_prefix(sums, (long long)seg, total, probe, lane, timeout);
+        hd.before_in_seg = before_in_seg;
+        hd.total = total;
+        // ---- the segment's count, published; the last segment of a group of 64 adds up the group
+        if (nseg && wave == 0) {
+            if (lane == 0) hw_store(&a.agg[seg], hw_pack(a.epoch, total));
+            if ((seg & 63) == 63) {
+                bool timeout = false;
+                sums_close<13>(sums, (long long)seg, total, lane, timeout);   // (<= STUFF_SEG per segment)
+                if (timeout && lane == 0) raise_error(a.status, a.err_epoch, JPG_ERR_HIP);
             }
+        }
+    };
+
+    auto back = [&](const Held &hd, const Probe &probe) {
+        const uint64_t seg = hd.seg;
+        const uint32_t total = hd.total;
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < WPT; k++) c += count_ff(hd.t[k]);
+        bool timeout = false;
+        if (wave == 0) {
+            uint64_t before = 0;
+            if (nseg) before = sums_prefix(sums, (long long)seg, probe, lane, timeout);
             if (lane == 0) sBefore = before;
         }
         if (__ballot(timeout) && lane == 0) raise_error(a.status, a.err_epoch, JPG_ERR_HIP);
         lds_barrier();
         JPG_STAMP(6);
         const uint64_t before_segs = sBefore;
+        const uint64_t q = seg * SEG_WORDS + (uint64_t)WPT * tid;
         if (seg == nloop - 1 && tid == 0) {
             a.status->nbits = nbits;
             a.status->scan_bytes = nbytes + before_segs + total;
-            // bits of the partial byte a non-final stripe leaves to its successor
+            // bits of the partial byte a non-final stripe leaves to its successor (no front follows the front of
+            // the last segment: its bits are still in sD)
             uint32_t tail = 0;
             if (!a.is_last && (tbits & 7)) {
                 const int r = (int)(8 * nbytes - seg * SEG_BITS);
@@ -655,32 +733,107 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             a.status->tail = tail;
             if (a.host_status) *a.host_status = *a.status;
         }
-        uint8_t *o = a.out + seg * STUFF_SEG + before_segs + 4 * WPT * tid + before_in_seg;
+        uint8_t *o = a.out + seg * STUFF_SEG + before_segs + 4 * WPT * tid + hd.before_in_seg;
         if (4 * (q + WPT) <= nbytes && c == 0 && ((reinterpret_cast<uintptr_t>(o) & 3) == 0)) {
             // common case: plain bytes, destination word-aligned
 #pragma unroll
-            for (int k = 0; k < WPT; k++) reinterpret_cast<uint32_t *>(o)[k] = __builtin_bswap32(t[k]);
+            for (int k = 0; k < WPT; k++) reinterpret_cast<uint32_t *>(o)[k] = __builtin_bswap32(hd.t[k]);
         } else {
 #pragma unroll
             for (int k = 0; k < 4 * WPT; k++) {
                 if (4 * q + k < nbytes) {
-                    const uint8_t b = (uint8_t)(t[k >> 2] >> (24 - 8 * (k & 3)));
+                    const uint8_t b = (uint8_t)(hd.t[k >> 2] >> (24 - 8 * (k & 3)));
                     *o++ = b;
                     if (b == 0xff) *o++ = 0;
                 }
             }
         }
-        lds_barrier();
         JPG_STAMP(7);
-        if (ticketer) sSeg = ticket;
-        lds_barrier();
-        seg = sSeg;
+    };
+
+    Probe asked{0, 0, 0};
+    if (!STUFF) {
+        Held hd;
+        for (uint64_t seg = wg; seg < nloop; seg += nwg) front(seg, ahead(seg), hd, false, 0, asked);
+        return;
     }
+    auto next_segment = [&]() {
+        if (ticketer) {
+            uint32_t seg32 = ticket;
+            if (TEAMS) {
+                draw_window();
+                draw_publish();
+                const uint32_t round = ticket / TEAM, idx = ticket & (TEAM - 1);
+                uint64_t w = ((uint64_t)(round + 1) << 32) | window;
+                if (idx) {
+                    const uint64_t *slot = &team_win[round % TEAM_RING];
+                    uint32_t spin = 0;
+                    for (;;) {
+                        w = hw_load(slot);
+                        if ((uint32_t)(w >> 32) == round + 1) break;
+                        if (++spin >= SPIN_LIMIT || (uint32_t)(w >> 32) > round + 1) {   // (never: the leader is running)
+                            raise_error(a.status, a.err_epoch, JPG_ERR_HIP);
+                            w = 0xffffffffull / TEAM;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                const uint64_t seg = (w & 0xffffffffull) * TEAM + idx;
+                seg32 = seg < 0xffffffffull ? (uint32_t)seg : 0xffffffffu;
+            }
+            sSeg = seg32;
+        }
+        lds_barrier();
+        const uint64_t seg = sSeg;
+        lds_barrier();                                           // (sSeg may be written again)
+        // the next draw: a turn before its result is needed
+        if (seg < nloop) draw_begin();
+        JPG_STAMP(1);
+        return seg;
+    };
+    draw_begin();
+    // segments put in place that wait for their back, oldest first
+    Held ring[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH; j++) ring[j].valid = false;
+    uint64_t coming = next_segment();
+    Ahead ac{0, 0u};
+    if (coming < nloop) ac = ahead(coming);
+    for (;;) {
+        const bool have = coming < nloop;
+        bool any = have;
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) any = any || ring[j].valid;
+        if (!any) break;
+        const Held out = ring[0];
+#pragma unroll
+        for (int j = 0; j + 1 < DEPTH; j++) ring[j] = ring[j + 1];
+        ring[DEPTH - 1].valid = false;
+        if (have) {
+            const uint64_t seg = coming;
+            const Ahead af = ac;
+            coming = next_segment();
+            if (coming < nloop) ac = ahead(coming);
+            front(seg, af, ring[DEPTH - 1], out.valid, out.seg, asked);
+        } else if (out.valid) {
+            asked = ask(out.seg);
+        }
+        if (out.valid) back(out, asked);
+    }
+#ifdef JPG_TRACE
+    if (tid == 0 && a.trace && blockIdx.x < 4096)
+        for (int k = 0; k < 8; k++) a.trace[blockIdx.x * 8 + k] = stamps[k];
+#endif
     // the last workgroup of the image to leave puts the counters back to 0 for the next launch (every
     // workgroup has drawn its last ticket before it counts itself out)
-    if (STUFF && ticketer && atomicAdd(&a.ticket[1], 1u) == nwg - 1) {
-        __hip_atomic_store(&a.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&a.ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticketer) sSeg = atomicAdd(&a.ticket[1], 1u) == nwg - 1;
+    lds_barrier();
+    if (sSeg) {
+        if (TEAMS)
+            for (unsigned i = tid; i < ((nwg + TEAM - 1) / TEAM) * TEAM_WORDS; i += ST_THREADS)
+                __hip_atomic_store(&a.ticket[TEAM_BASE + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 2) __hip_atomic_store(&a.ticket[tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -765,12 +918,12 @@ hipError_t launch_entropy(const Geom &g, const int16_t *coef, const int16_t pred
     return hipGetLastError();
 }
 
-template <bool STUFF, int ST_THREADS>
+template <bool STUFF, int ST_THREADS, int DEPTH, bool TEAMS>
 static hipError_t launch_stream_threads(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last,
                                         uint8_t *out, size_t out_stride, hipStream_t s) {
     const int nimg = b.nimg > 0 ? b.nimg : 1;
     const int ngroups = (int)((b.nchunks + 63) / 64);
-    if (ngroups > MAX_GROUPS || !out || b.slot_words <= 0 || (STUFF && !b.sticket)) return hipErrorInvalidValue;
+    if (ngroups > MAX_GROUPS || !out || b.slot_words <= 0 || (STUFF && !b.sticket) || !b.gsum) return hipErrorInvalidValue;
     const size_t lds = (ngroups + 1) * sizeof(uint64_t);
     // As many workgroups as fit on an idle device at once (more would only queue up; fewer being resident,
     // because something else runs on the device, is harmless: segments are handed out in order by a ticket
@@ -788,7 +941,7 @@ static hipError_t launch_stream_threads(const EntropyBufs &b, uint64_t bit_offse
         int cus = 0, per_cu = 0;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<STUFF, ST_THREADS>, ST_THREADS,
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<STUFF, ST_THREADS, DEPTH, TEAMS>, ST_THREADS,
                                                              (size_t)cls * LDS_CLASS);
         if (e != hipSuccess) return e;
         resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
@@ -804,18 +957,22 @@ static hipError_t launch_stream_threads(const EntropyBufs &b, uint64_t bit_offse
     // only queue up (segments are handed out by ticket, so every wait is for a workgroup that is running or done)
     size_t wpi = cap / nimg > 0 ? cap / nimg : 1;
     if (wpi > b.nseg_cap) wpi = b.nseg_cap ? b.nseg_cap : 1;
-    StreamArgs a{b.sparse, b.clen, b.nchunks, ngroups, (int)wpi, b.cstride, (size_t)b.slot_words, out_stride, b.nseg_cap, b.nseg_cap / 64 + 1,
+    if (TEAMS && wpi > (size_t)MAX_TEAMS * TEAM) wpi = (size_t)MAX_TEAMS * TEAM;
+    const size_t gstride = (size_t)(b.cstride / 64);
+    hipLaunchKernelGGL(k_group_sums, dim3((unsigned)((ngroups + 15) / 16), (unsigned)nimg), dim3(1024), 0, s, b.clen, b.nchunks,
+                       b.cstride, ngroups, b.gsum, gstride);
+    StreamArgs a{b.sparse, b.clen, b.gsum, gstride, b.nchunks, ngroups, (int)wpi, b.cstride, (size_t)b.slot_words, out_stride, b.nseg_cap, b.nseg_cap / 64 + 1,
                  b.nseg_cap / 4096 + 1, b.status, (uint32_t)(bit_offset & 7), head_bits, STUFF ? b.chain : nullptr, is_last, b.sagg, b.sgrp, b.shyp,
                  b.sticket, b.stuff_epoch, b.epoch, out, b.host_status, b.trace};
-    hipLaunchKernelGGL((k_stream<STUFF, ST_THREADS>), dim3((unsigned)(wpi * nimg)), dim3(ST_THREADS), lds, s, a);
+    hipLaunchKernelGGL((k_stream<STUFF, ST_THREADS, DEPTH, TEAMS>), dim3((unsigned)(wpi * nimg)), dim3(ST_THREADS), lds, s, a);
     return hipGetLastError();
 }
 
 template <bool STUFF>
 static hipError_t launch_stream(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, uint8_t *out,
                                 size_t out_stride, hipStream_t s) {
-    if (b.nimg > 1) return launch_stream_threads<STUFF, ST_THREADS_BATCH>(b, bit_offset, head_bits, is_last, out, out_stride, s);
-    return launch_stream_threads<STUFF, ST_THREADS_SINGLE>(b, bit_offset, head_bits, is_last, out, out_stride, s);
+    if (b.nimg > 1) return launch_stream_threads<STUFF, ST_THREADS_BATCH, 1, false>(b, bit_offset, head_bits, is_last, out, out_stride, s);
+    return launch_stream_threads<STUFF, ST_THREADS_SINGLE, ST_DEPTH_SINGLE, STUFF>(b, bit_offset, head_bits, is_last, out, out_stride, s);
 }
 
 hipError_t launch_stuff(const EntropyBufs &b, uint64_t bit_offset, uint8_t head_bits, int is_last, hipStream_t s) {

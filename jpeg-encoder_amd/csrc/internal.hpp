@@ -41,6 +41,8 @@ constexpr int CHUNK_STRIDE_WORDS = CHUNK_BLOCKS * SLOT_WORDS_PER_BLOCK;
 static_assert(SLOT_WORDS_PER_BLOCK * 32 >= MAX_BLOCK_BITS + 1, "chunk slot too small");
 // byte-stuffing works on segments of this many unstuffed bytes
 constexpr int STUFF_SEG = 4096;
+// words of the ticket counters of the stuffing kernel for a single image (a batch: two per image)
+constexpr int TICKET_WORDS_SINGLE = 64 + 64 * 64;
 // images one launch of the coding and stream kernels can take (jpg_max_batch): the pixel pointers of a launch
 // travel in the coding kernel's argument block
 constexpr int MAX_BATCH_IMAGES = 64;
@@ -111,11 +113,12 @@ struct EntropyBufs {
     size_t bits_cap;       // bytes
     // running sums of the 0xFF counts of the stuffing segments (see entropy.hip); each word is
     // {epoch:14 | valid:1 | value:49} written by one 8-byte store
+    uint32_t *gsum;        // [nimg][cstride / 64] bits of each group of 64 chunks (working array of the stream kernels)
     uint64_t *sagg;        // [nimg][nseg_cap] 0xFF bytes of the segment
     uint64_t *sgrp;        // [nimg][nseg_cap/64 + 1] ... of a group of 64 segments
     uint64_t *shyp;        // [nimg][nseg_cap/4096 + 1] ... of a hyper-group of 64 groups
     uint32_t stuff_epoch;  // their generation (1..16383)
-    uint32_t *sticket;     // [nimg][2] segment ticket counter and exit counter of the stuffing kernel; zero between launches
+    uint32_t *sticket;     // [nimg][2], at least TICKET_WORDS_SINGLE words: ticket counters of the stuffing kernel; zero between launches
     size_t stuff_grid;     // workgroups of the stream kernels (0 = as many as fit on the device)
     uint8_t *scan;         // [nimg][scan_stride] stuffed streams
     size_t scan_stride;    // bytes per image

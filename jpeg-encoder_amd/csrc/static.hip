@@ -62,7 +62,7 @@ size_t up256(size_t n) { return (n + 255) / 256 * 256; }
 // Where everything sits in the array for an image of geometry g (byte offsets, all multiples of 256).  The
 // small records come first so that one memset clears what must start at zero.
 struct Layout {
-    size_t status, ticket, agg, grp, hyp, clen, clear_bytes, sparse, total;
+    size_t status, ticket, agg, grp, hyp, clen, clear_bytes, gsum, sparse, total;
     long long nchunks, cstride;
     int slot_words;
     size_t nseg;
@@ -76,12 +76,13 @@ Layout layout_of(const Geom &g) {
     l.nseg = worst_segments((size_t)g.nblocks);
     size_t at = 0;
     l.status = at; at += up256(sizeof(DevStatus));
-    l.ticket = at; at += 256;
+    l.ticket = at; at += up256(TICKET_WORDS_SINGLE * sizeof(uint32_t));
     l.agg = at; at += up256(l.nseg * sizeof(uint64_t));
     l.grp = at; at += up256((l.nseg / 64 + 1) * sizeof(uint64_t));
     l.hyp = at; at += up256((l.nseg / 4096 + 1) * sizeof(uint64_t));
     l.clen = at; at += up256((size_t)l.cstride * sizeof(uint32_t));
     l.clear_bytes = at;
+    l.gsum = at; at += up256((size_t)(l.cstride / 64) * sizeof(uint32_t));
     l.sparse = at; at += (size_t)l.cstride * (size_t)l.slot_words * sizeof(uint32_t);
     l.total = at;
     return l;
@@ -137,6 +138,7 @@ extern "C" int jpg_encode_device_static(int device, int dct_algo, int ra, int rb
     eb.cstride = l.cstride;
     eb.slot_words = l.slot_words;
     eb.clen = reinterpret_cast<uint32_t *>(b8 + l.clen);
+    eb.gsum = reinterpret_cast<uint32_t *>(b8 + l.gsum);
     eb.sparse = reinterpret_cast<uint32_t *>(b8 + l.sparse);
     eb.epoch = 1;
     eb.status = reinterpret_cast<DevStatus *>(b8 + l.status);
