@@ -15,11 +15,12 @@
 // wave depends on another one.
 //
 // k_stream<true> (byte stuffing) and k_stream<false> (dense copy) read the
-// concatenation of the chunks: a workgroup sums the chunk lengths to find the
-// chunks under its 4 KiB segment of the stream and gathers the bits, shifted to
-// their place, straight from the chunk slots.  Stuffing then inserts 0x00 after
-// every 0xFF; the output offset of a segment comes from three levels of running
-// sums of the 0xFF counts, published by the segments before it.
+// concatenation of the chunks: from the running sums of the chunk lengths (per
+// group of 64 chunks: k_group_sums) a workgroup finds the chunks under its 4 KiB
+// segment of the stream and gathers the bits, shifted to their place, straight
+// from the chunk slots.  Stuffing then inserts 0x00 after every 0xFF; the output
+// offset of a segment comes from three levels of running sums of the 0xFF
+// counts, published by the segments before it.
 #include <atomic>
 
 #include "coding.hpp"
@@ -402,21 +403,26 @@ __global__ __launch_bounds__(1024) void k_group_sums(const uint32_t *__restrict_
 // dependent steps, and more waves keep the per-thread instruction count of every step small); 256 for a batch,
 // which is stuffed beside the coding kernel of the next batch: one wave per SIMD, 64 registers and under 8 KiB of
 // LDS fit into what four workgroups of the coding kernel leave free on a CU.
-constexpr int ST_THREADS_SINGLE = 512, ST_THREADS_BATCH = 256;
+#ifndef JPG_ST_THREADS_SINGLE
+#define JPG_ST_THREADS_SINGLE 512
+#endif
+constexpr int ST_THREADS_SINGLE = JPG_ST_THREADS_SINGLE, ST_THREADS_BATCH = 256;
 // teams of workgroups that share a ticket counter (words of an image's counters: [0] the image's counter, [1] workgroups
 // that have left, from TEAM_BASE on a record of TEAM_WORDS per team)
 constexpr int TEAM = 32, TEAM_RING = 8, TEAM_WORDS = 64, TEAM_BASE = 64, MAX_TEAMS = (TICKET_WORDS_SINGLE - TEAM_BASE) / TEAM_WORDS;
+// fronts of later segments between a segment's front and its back: two for a single image (measured: 1 % better than
+// one; 256 threads per segment 15 % worse than 512), one for a batch (fewer registers)
 #ifndef JPG_ST_DEPTH
-#define JPG_ST_DEPTH 1
+#define JPG_ST_DEPTH 2
 #endif
 constexpr int ST_DEPTH_SINGLE = JPG_ST_DEPTH;
 
-// STUFF: byte stuffing of the (shifted) stream into a.out, a workgroup per segment of
-// STUFF_SEG stream bytes (blockIdx.x, + gridDim.x, ...).  !STUFF: the stream itself, dense.
-// Dynamic LDS: (ngroups + 1) 64-bit prefix sums of the chunk lengths per group.
-// The kernel is a chain of short dependent steps.  Four waves per workgroup: one per SIMD, which is what fits
-// beside the workgroups of the coding kernel of the next batch (see launch_stream).
+// STUFF: byte stuffing of the (shifted) stream into a.out, a workgroup per segment of STUFF_SEG stream bytes at a
+// time (segments are drawn from ticket counters).  !STUFF: the stream itself, dense (segments blockIdx.x,
+// + gridDim.x, ...).  Dynamic LDS: (ngroups + 1) 64-bit prefix sums of the chunk lengths per group.
+// The work on a segment is a chain of short dependent steps; a workgroup works on several segments in turn.
 // DEPTH: fronts of later segments between a segment's front and its back (see the three steps below).
+// TEAMS: ticket counters per team of workgroups (single images).
 template <bool STUFF, int ST_THREADS, int DEPTH, bool TEAMS>
 // (at most 64 registers: eight waves per SIMD when it has the device to itself)
 __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_stream(StreamArgs a) {

@@ -141,6 +141,28 @@ def test_more_images_than_stuffing_workgroups(J, oracle, monkeypatch):
     enc.close()
 
 
+@pytest.mark.parametrize("grid", [1, 3, 33, 40])
+def test_single_image_stuffed_by_few_workgroups(J, oracle, monkeypatch, grid):
+    """The stuffing kernel of a single image draws its segments in teams of 32 workgroups, three segments in
+    work per workgroup: with 1, 3, 33 or 40 workgroups (one team, a team and a single workgroup, a team and a
+    quarter) every workgroup takes many turns, and the scan must not change (noise: several hundred segments, many
+    0xFF bytes)."""
+    import torch
+    monkeypatch.setenv("JPG_STUFF_GRID", str(grid))
+    w, h = 2048, 1200
+    rows = J.host.synth_bgr(w, h, seed=300 + grid, noise_only=True)
+    t = torch.from_numpy(rows).cuda()
+    torch.cuda.synchronize()
+    enc = J.Encoder((4, 2, 0), "bin-dct")
+    want = _ref(oracle, rows, w, h, (4, 2, 0), "bin-dct").stuffed_scan()
+    assert want.size > 300 * 4096
+    for _ in range(2):                                        # (the second launch finds the counters as the first left them)
+        enc.encode_device_async(t.data_ptr(), w, h, rows.shape[1], True)
+        _, n = enc.finish()
+        np.testing.assert_array_equal(enc.scan(n), want)
+    enc.close()
+
+
 def test_row_stride_beyond_the_offset_range_is_refused(J):
     """The kernels address a tile's rows with 32-bit offsets: a stride at which 16 rows reach 2^31 bytes is refused
     (JPG_ERR_TOO_LARGE) before anything is launched."""
