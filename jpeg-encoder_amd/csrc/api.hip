@@ -649,6 +649,7 @@ static int prepare_slot(jpg_ctx *c, bool coded) {
     sl.eb.host_status = sl.h_status_alt ? sl.h_status_alt : sl.h_status;
     sl.dense_valid = false;
     sl.tail_known = false;
+    sl.eb.gsum_ready = false;
     sl.tiles = coded;
     // The small bit window while the tiles of the encode before fitted it with room to spare (half of it on average)
     sl.eb.small_window = coded && coded_small_window(c->g, c->algo) &&
@@ -687,6 +688,7 @@ static int queue_stuff(jpg_ctx *c, uint64_t bit_offset, uint8_t head_bits, int i
     }
     sl.eb.stuff_epoch++;
     sl.eb.host_status = sl.h_status_alt ? sl.h_status_alt : sl.h_status;
+    sl.eb.gsum_ready = sl.tail_known;    // (the tail kernel leaves the sums of the groups of chunks behind)
     HIP_TRY(c, launch_stuff(sl.eb, bit_offset, head_bits, is_last, st));
     HIP_TRY(c, hipEventRecord(sl.s_done, st));
     sl.busy = true;
@@ -708,6 +710,7 @@ static int make_dense(jpg_ctx *c) {
     if (sl.dense_valid) return JPG_OK;
     if (int e = ensure_dense(c)) return e;
     sl.eb.host_status = sl.h_status;
+    sl.eb.gsum_ready = sl.tail_known;
     HIP_TRY(c, launch_dense(sl.eb, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     sl.dense_valid = true;

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         const int img = blockIdx.x / a.wpi;
         a.sparse += (size_t)img * a.cstride * a.slot_words;
         a.clen += img * a.cstride;
-        a.gsum += img * a.gsum_stride;
+        if (a.gsum) a.gsum += img * a.gsum_stride;
         a.out += img * a.out_stride;
         a.agg += img * a.agg_stride;
         a.grp += img * a.grp_stride;
@@ -471,8 +471,29 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     unsigned long long last_stamp = wall_clock64();
 #endif
 
-    // ---- bits per group (summed up by k_group_sums, queued before this kernel), then their running sums
-    for (int g = tid; g < a.ngroups; g += ST_THREADS) sG[g] = a.gsum[g];
+    // ---- bits per group, then their running sums.  A single image: summed up by a kernel queued before this one
+    // (k_group_sums, or k_tail for a stripe of a chain; a thousand workgroups adding up the same lengths took a fifth
+    // of the kernel's time); a batch: the few workgroups of an image add up its lengths themselves.
+    for (int g = tid; g < a.ngroups; g += ST_THREADS) {
+        if (a.gsum) { sG[g] = a.gsum[g]; continue; }
+        const long long c0 = (long long)g * 64;
+        uint32_t sum = 0;
+        if (c0 + 64 <= a.nchunks) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.clen + c0);
+            uint4 v[8];                                          // two batches: the kernel has to stay within 64 registers
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = p[k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) sum += v[k].x + v[k].y + v[k].z + v[k].w;
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = p[8 + k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) sum += v[k].x + v[k].y + v[k].z + v[k].w;
+        } else {
+            for (long long c = c0; c < a.nchunks; c++) sum += a.clen[c];
+        }
+        sG[g] = sum;
+    }
     lds_barrier();
     JPG_STAMP(0);
     const int per = (a.ngroups + ST_THREADS - 1) / ST_THREADS;
@@ -850,18 +871,35 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 // chain_slot: where a stripe of a chain publishes both for the stripes after it (host memory shared by the GPUs).
 __global__ __launch_bounds__(1024) void k_tail(const uint32_t *__restrict__ sparse, const uint32_t *__restrict__ clen,
                                                long long nchunks, size_t slot_words, DevStatus *status, DevStatus *host_status,
-                                               ChainMail *chain_slot, uint32_t chain_tag) {
+                                               ChainMail *chain_slot, uint32_t chain_tag, uint32_t *__restrict__ gsum) {
     __shared__ uint64_t sSum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the lengths, 16 bytes per load (the array is padded to a multiple of 64 words; clen is 16-byte aligned)
+    // (16 lanes in a row hold a group of 64 chunks: their sum goes to gsum for the stuffing kernel; the array is
+    // padded with zeros to whole groups)
     uint64_t sum = 0;
-    const long long quads = nchunks >> 2;
+    const long long quads = (nchunks + 63) / 64 * 16;
     const uint4 *q = reinterpret_cast<const uint4 *>(clen);
-    for (long long i = tid; i < quads; i += 1024) {
-        const uint4 v = q[i];
-        sum += (uint64_t)v.x + v.y + v.z + v.w;
+    for (long long i = tid; i - tid < quads; i += 1024) {      // (whole waves: the row sums below take all lanes)
+        uint4 v{0, 0, 0, 0};
+        if (i < quads) {
+            v = q[i];
+            const long long c = i * 4;                           // (what lies behind the last chunk is not defined)
+            if (c + 3 >= nchunks) {
+                if (c + 0 >= nchunks) v.x = 0;
+                if (c + 1 >= nchunks) v.y = 0;
+                if (c + 2 >= nchunks) v.z = 0;
+                v.w = 0;
+            }
+        }
+        uint32_t part = v.x + v.y + v.z + v.w;
+        sum += part;
+        part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x111, 0xf, 0xf, false);   // row_shr:1
+        part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x112, 0xf, 0xf, false);   // row_shr:2
+        part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x114, 0xf, 0xf, false);   // row_shr:4
+        part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x118, 0xf, 0xf, false);   // row_shr:8
+        if (gsum && (tid & 15) == 15 && i < quads) gsum[i >> 4] = part;
     }
-    if (tid < (int)(nchunks & 3)) sum += clen[(quads << 2) + tid];
     sum = wave_sum64(sum);
     if (lane == 0) sSum[wave] = sum;
     __syncthreads();
@@ -893,7 +931,7 @@ __global__ __launch_bounds__(1024) void k_tail(const uint32_t *__restrict__ spar
 hipError_t launch_tail(const EntropyBufs &b, hipStream_t s) {
     if ((b.nimg > 0 ? b.nimg : 1) != 1 || b.slot_words <= 0) return hipErrorInvalidValue;   // single images only
     hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), 0, s, b.sparse, b.clen, b.nchunks, (size_t)b.slot_words, b.status,
-                       b.host_status, b.chain_slot, b.chain_tag);
+                       b.host_status, b.chain_slot, b.chain_tag, b.gsum);
     return hipGetLastError();
 }
 
@@ -965,9 +1003,11 @@ static hipError_t launch_stream_threads(const EntropyBufs &b, uint64_t bit_offse
     if (wpi > b.nseg_cap) wpi = b.nseg_cap ? b.nseg_cap : 1;
     if (TEAMS && wpi > (size_t)MAX_TEAMS * TEAM) wpi = (size_t)MAX_TEAMS * TEAM;
     const size_t gstride = (size_t)(b.cstride / 64);
-    hipLaunchKernelGGL(k_group_sums, dim3((unsigned)((ngroups + 15) / 16), (unsigned)nimg), dim3(1024), 0, s, b.clen, b.nchunks,
-                       b.cstride, ngroups, b.gsum, gstride);
-    StreamArgs a{b.sparse, b.clen, b.gsum, gstride, b.nchunks, ngroups, (int)wpi, b.cstride, (size_t)b.slot_words, out_stride, b.nseg_cap, b.nseg_cap / 64 + 1,
+    const bool pre = nimg == 1;
+    if (pre && !b.gsum_ready)
+        hipLaunchKernelGGL(k_group_sums, dim3((unsigned)((ngroups + 15) / 16), 1u), dim3(1024), 0, s, b.clen, b.nchunks,
+                           b.cstride, ngroups, b.gsum, gstride);
+    StreamArgs a{b.sparse, b.clen, pre ? b.gsum : nullptr, gstride, b.nchunks, ngroups, (int)wpi, b.cstride, (size_t)b.slot_words, out_stride, b.nseg_cap, b.nseg_cap / 64 + 1,
                  b.nseg_cap / 4096 + 1, b.status, (uint32_t)(bit_offset & 7), head_bits, STUFF ? b.chain : nullptr, is_last, b.sagg, b.sgrp, b.shyp,
                  b.sticket, b.stuff_epoch, b.epoch, out, b.host_status, b.trace};
     hipLaunchKernelGGL((k_stream<STUFF, ST_THREADS, DEPTH, TEAMS>), dim3((unsigned)(wpi * nimg)), dim3(ST_THREADS), lds, s, a);

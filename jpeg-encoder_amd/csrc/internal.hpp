@@ -113,7 +113,8 @@ struct EntropyBufs {
     size_t bits_cap;       // bytes
     // running sums of the 0xFF counts of the stuffing segments (see entropy.hip); each word is
     // {epoch:14 | valid:1 | value:49} written by one 8-byte store
-    uint32_t *gsum;        // [nimg][cstride / 64] bits of each group of 64 chunks (working array of the stream kernels)
+    uint32_t *gsum;        // [cstride / 64] bits of each group of 64 chunks of a single image (working array of the stream kernels)
+    bool gsum_ready;       // ... as left by the tail kernel queued before the stream kernel
     uint64_t *sagg;        // [nimg][nseg_cap] 0xFF bytes of the segment
     uint64_t *sgrp;        // [nimg][nseg_cap/64 + 1] ... of a group of 64 segments
     uint64_t *shyp;        // [nimg][nseg_cap/4096 + 1] ... of a hyper-group of 64 groups

@@ -18,8 +18,8 @@ for p in glob.glob(sys.argv[1] + "/*kernel_trace.csv"):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name.split("(")[0][:40], r.get("Queue_Id", "?")))
 rows.sort()
 n = int(sys.argv[2])
-# kernels of one pass: 8 per stripe (k_mcu_dc, k_coded, k_tail, k_chain_place, k_stream, k_chain_offset, k_chain_copy,
-# k_chain_done); the last pass starts at the n-th last k_mcu_dc
+# kernels of one pass: 9 per stripe (k_mcu_dc, k_coded, k_tail, k_chain_place, k_group_sums, k_stream, k_chain_offset,
+# k_chain_copy, k_chain_done); the last pass starts at the n-th last k_mcu_dc
 starts = [i for i, r in enumerate(rows) if r[2].startswith("k_mcu_dc")]
 last = rows[starts[-n]:]
 t0 = last[0][0]
