@@ -401,7 +401,7 @@ __global__ __launch_bounds__(1024) void k_group_sums(const uint32_t *__restrict_
 
 // Threads per segment: 512 for a single image, whose stuffing nothing else hides (the kernel is a chain of short
 // dependent steps, and more waves keep the per-thread instruction count of every step small); 256 for a batch,
-// which is stuffed beside the coding kernel of the next batch: one wave per SIMD, 64 registers and under 8 KiB of
+// which is stuffed beside the coding kernel of the next batch: one wave per SIMD, 76 registers and under 8 KiB of
 // LDS fit into what four workgroups of the coding kernel leave free on a CU.
 #ifndef JPG_ST_THREADS_SINGLE
 #define JPG_ST_THREADS_SINGLE 512
@@ -415,6 +415,15 @@ constexpr int TEAM = 32, TEAM_RING = 8, TEAM_WORDS = 64, TEAM_BASE = 64, MAX_TEA
 #ifndef JPG_ST_DEPTH
 #define JPG_ST_DEPTH 2
 #endif
+// waves per SIMD the register budget of the stuffing kernel is set for.  It needs 76 registers: within 64 (eight
+// waves) it spills, which costs a batch of small images 5 %; with six waves (single images: three workgroups of
+// 512 threads per CU) or four (batches: one wave per SIMD beside the coding kernel's) it does not, at the same speed.
+#ifndef JPG_ST_WAVES_BATCH
+#define JPG_ST_WAVES_BATCH 4
+#endif
+#ifndef JPG_ST_WAVES_SINGLE
+#define JPG_ST_WAVES_SINGLE 6
+#endif
 constexpr int ST_DEPTH_SINGLE = JPG_ST_DEPTH;
 
 // STUFF: byte stuffing of the (shifted) stream into a.out, a workgroup per segment of STUFF_SEG stream bytes at a
@@ -424,8 +433,9 @@ constexpr int ST_DEPTH_SINGLE = JPG_ST_DEPTH;
 // DEPTH: fronts of later segments between a segment's front and its back (see the three steps below).
 // TEAMS: ticket counters per team of workgroups (single images).
 template <bool STUFF, int ST_THREADS, int DEPTH, bool TEAMS>
-// (at most 64 registers: eight waves per SIMD when it has the device to itself)
-__global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_stream(StreamArgs a) {
+// (JPG_ST_WAVES_*: waves per SIMD the register budget is set for)
+__global__ __launch_bounds__(ST_THREADS)
+__attribute__((amdgpu_waves_per_eu(ST_THREADS == ST_THREADS_BATCH ? JPG_ST_WAVES_BATCH : JPG_ST_WAVES_SINGLE, 8))) void k_stream(StreamArgs a) {
     constexpr int ST_WAVES = ST_THREADS / 64;
     constexpr int WPT = SEG_WORDS / ST_THREADS;   // 32-bit words of the segment per thread
     constexpr int GATHER_ROUNDS = (DENSE_WORDS + 2 * 132 + ST_THREADS - 1) / ST_THREADS;
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         uint32_t sum = 0;
         if (c0 + 64 <= a.nchunks) {
             const uint4 *p = reinterpret_cast<const uint4 *>(a.clen + c0);
-            uint4 v[8];                                          // two batches: the kernel has to stay within 64 registers
+            uint4 v[8];                                          // two batches of loads: fewer registers
 #pragma unroll
             for (int k = 0; k < 8; k++) v[k] = p[k];
 #pragma unroll
@@ -641,9 +651,6 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         for (int k = tid; k < DENSE_WORDS; k += ST_THREADS) sD[k] = 0;
         lds_barrier();
         JPG_STAMP(3);
-        // (a wave's loads return in the order they were issued: asked for here, the counts arrive with the words
-        // gathered below and cost no wait of their own)
-        if (STUFF && wanted) asked = ask(ask_seg);
         if (STUFF) draw_window();
         {
             // thread t takes wanted words t * rounds .. t * rounds + rounds - 1: one search, then a walk
@@ -675,6 +682,9 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             }
         }
         if (STUFF) draw_publish();                               // (the words gathered have arrived, and the window before them)
+        // the counts the back that follows needs: asked for here, behind the phase that needs the most registers,
+        // they arrive while the segment is counted
+        if (STUFF && wanted) asked = ask(ask_seg);
         lds_barrier();
         JPG_STAMP(4);
 
@@ -716,6 +726,7 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             if (w < wave) before_in_seg += p;
             total += p;
         }
+        total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
         hd.before_in_seg = before_in_seg;
         hd.total = total;
         // ---- the segment's count, published; the last segment of a group of 64 adds up the group
@@ -812,7 +823,8 @@ __global__ __launch_bounds__(ST_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             sSeg = seg32;
         }
         lds_barrier();
-        const uint64_t seg = sSeg;
+        // (the same in every lane: kept in scalar registers, as is what follows from it)
+        const uint64_t seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)sSeg);
         lds_barrier();                                           // (sSeg may be written again)
         // the next draw: a turn before its result is needed
         if (seg < nloop) draw_begin();
@@ -980,22 +992,28 @@ static hipError_t launch_stream_threads(const EntropyBufs &b, uint64_t bit_offse
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    static std::atomic<int> cus_cache[64] = {};
     long long resident = dev >= 0 && dev < 64 ? resident_cache[dev][cls].load(std::memory_order_relaxed) : 0;
-    if (resident == 0) {
-        int cus = 0, per_cu = 0;
+    int cus = dev >= 0 && dev < 64 ? cus_cache[dev].load(std::memory_order_relaxed) : 0;
+    if (resident == 0 || cus == 0) {
+        int per_cu = 0;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e == hipSuccess)
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<STUFF, ST_THREADS, DEPTH, TEAMS>, ST_THREADS,
                                                              (size_t)cls * LDS_CLASS);
         if (e != hipSuccess) return e;
+        if (cus < 1) cus = 1;
         resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
-        if (dev >= 0 && dev < 64) resident_cache[dev][cls].store(resident, std::memory_order_relaxed);
+        if (dev >= 0 && dev < 64) {
+            resident_cache[dev][cls].store(resident, std::memory_order_relaxed);
+            cus_cache[dev].store(cus, std::memory_order_relaxed);
+        }
     }
     size_t cap = (size_t)resident;
-    // A batch is stuffed while the coding kernel of the next batch runs: two workgroups per CU take nothing from
-    // it; with more, the two kernels compete for the slots (7680x4320 batches: 865 K MP/s with two per CU, 828 K
-    // with eight, 856 K with one for every second CU).
-    if (ST_THREADS == ST_THREADS_BATCH && cap > (size_t)resident / 4) cap = (size_t)resident / 4;
+    // A batch is stuffed while the coding kernel of the next batch runs: up to two workgroups per CU take nothing
+    // from it; with more, the two kernels compete for the slots (7680x4320 batches: 865 K MP/s with two per CU,
+    // 828 K with eight, 856 K with one for every second CU; one per CU: as two).
+    if (ST_THREADS == ST_THREADS_BATCH && cap > 2 * (size_t)cus) cap = 2 * (size_t)cus;
     if (b.stuff_grid && b.stuff_grid < cap) cap = b.stuff_grid;
     // workgroups per image; at least one, however many images there are: more workgroups than are resident at once
     // only queue up (segments are handed out by ticket, so every wait is for a workgroup that is running or done)
