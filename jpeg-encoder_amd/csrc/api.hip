@@ -385,7 +385,10 @@ static int ensure_entropy(jpg_ctx *c, bool coded) {
         if (sl.h_status) (void)hipHostFree(sl.h_status);
         sl.eb.status = nullptr; sl.h_status = nullptr; sl.cap_status = 0;
         HIP_TRY(c, hipMalloc((void **)&sl.eb.status, nimg * sizeof(DevStatus)));
-        HIP_TRY(c, hipMemset(sl.eb.status, 0, nimg * sizeof(DevStatus)));
+        // (cleared on the context's stream and waited for: the streams of a context do not wait for the default
+        // stream, on which a plain hipMemset may still be pending when the kernels that use the memory start)
+        HIP_TRY(c, hipMemsetAsync(sl.eb.status, 0, nimg * sizeof(DevStatus), c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipHostMalloc((void **)&sl.h_status, nimg * sizeof(DevStatus), hipHostMallocDefault));
         memset(sl.h_status, 0, nimg * sizeof(DevStatus));
         sl.cap_status = nimg;
@@ -393,7 +396,8 @@ static int ensure_entropy(jpg_ctx *c, bool coded) {
     }
     if (std::max<size_t>(2 * nimg, TICKET_WORDS_SINGLE) > sl.cap_ticket) {
         if ((e = grow(c, sl.eb.sticket, sl.cap_ticket, std::max<size_t>(2 * nimg, TICKET_WORDS_SINGLE)))) return e;
-        HIP_TRY(c, hipMemset(sl.eb.sticket, 0, sl.cap_ticket * sizeof(uint32_t)));   // the kernel leaves them at 0
+        HIP_TRY(c, hipMemsetAsync(sl.eb.sticket, 0, sl.cap_ticket * sizeof(uint32_t), c->stream));   // the kernel leaves them at 0
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     // the hand-off words are laid out per image with the stride nseg: a change of either relocates them
     if (nseg != sl.eb.nseg_cap || nimg * nseg > sl.cap_sagg) {
@@ -1043,7 +1047,8 @@ extern "C" int jpg_chain_setup(jpg_ctx *c, int rank, int world, void *mailbox, v
     if (!ch.h_status) HIP_TRY(c, hipHostMalloc((void **)&ch.h_status, 2 * sizeof(DevStatus), hipHostMallocDefault));
     for (hipEvent_t &e : ch.ev)
         if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(c, hipMemset(ch.d_params, 0, 2 * sizeof(ChainParams)));
+    HIP_TRY(c, hipMemsetAsync(ch.d_params, 0, 2 * sizeof(ChainParams), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     memset(ch.h_params, 0, 2 * sizeof(ChainParams));
     memset(ch.h_status, 0, 2 * sizeof(DevStatus));
     ch.mail = static_cast<ChainMail *>(mail_dev);

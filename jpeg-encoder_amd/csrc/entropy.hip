@@ -466,7 +466,7 @@ __attribute__((amdgpu_waves_per_eu(ST_THREADS == ST_THREADS_BATCH ? JPG_ST_WAVES
     __shared__ int sW0[TABLE];             // first word wanted from each chunk
     __shared__ uint32_t sD[DENSE_WORDS];   // the segment's bits in place
     __shared__ uint32_t s[ST_WAVES];
-    __shared__ uint64_t sBefore;
+    __shared__ uint64_t sBefore[2];        // (in turn: two backs may follow each other with one barrier between them)
     __shared__ uint32_t sSeg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Stuffing: segments are handed out by a ticket counter, lowest first, so every segment with a lower
@@ -740,6 +740,7 @@ __attribute__((amdgpu_waves_per_eu(ST_THREADS == ST_THREADS_BATCH ? JPG_ST_WAVES
         }
     };
 
+    int backs = 0;
     auto back = [&](const Held &hd, const Probe &probe) {
         const uint64_t seg = hd.seg;
         const uint32_t total = hd.total;
@@ -747,15 +748,16 @@ __attribute__((amdgpu_waves_per_eu(ST_THREADS == ST_THREADS_BATCH ? JPG_ST_WAVES
 #pragma unroll
         for (int k = 0; k < WPT; k++) c += count_ff(hd.t[k]);
         bool timeout = false;
+        backs ^= 1;
         if (wave == 0) {
             uint64_t before = 0;
             if (nseg) before = sums_prefix(sums, (long long)seg, probe, lane, timeout);
-            if (lane == 0) sBefore = before;
+            if (lane == 0) sBefore[backs] = before;
         }
         if (__ballot(timeout) && lane == 0) raise_error(a.status, a.err_epoch, JPG_ERR_HIP);
         lds_barrier();
         JPG_STAMP(6);
-        const uint64_t before_segs = sBefore;
+        const uint64_t before_segs = sBefore[backs];
         const uint64_t q = seg * SEG_WORDS + (uint64_t)WPT * tid;
         if (seg == nloop - 1 && tid == 0) {
             a.status->nbits = nbits;

@@ -54,6 +54,7 @@ def chain_scan(rows, w, h, stride, ratio, algo, vs, bottom_up, n):
         es[k].stripe_device(dev[k].data_ptr(), w, plan[k][1] - plan[k][0], stride, bottom_up)
         es[k].chain_pass_async(mask)
     res = {k: es[k].chain_pass_finish() for k in reversed(active)}
+    chain_scan.last = {"stripes": n, "rows": [plan[k] for k in active], "results": {k: res[k] for k in active}}
     total = res[0][4]
     out = np.zeros(total, np.uint8)
     if total:
@@ -88,6 +89,8 @@ for it in range(cases):
     want = refcpu.RefImage.from_bgr(rows, w, h, stride, ratio, ref_algo, bottom_up=bottom_up).encode().stuffed_scan()
     enc = encs.setdefault((ratio, algo), J.Encoder(ratio, algo))
     mode = int(rng.integers(6))
+    if os.environ.get("FUZZ_CHAIN_BIAS") and rng.random() < 0.5:
+        mode = 5                                                # (more of the cases through the stripe chain)
     tile_w = 1024 if (hs, vs) == (2, 1) else 512
     if mode == 5 and w >= tile_w:
         got = chain_scan(rows, w, h, stride, ratio, algo, vs, bottom_up, int(rng.integers(1, 7)))
@@ -140,7 +143,10 @@ for it in range(cases):
         got = enc.batch_scan(k)
     if not np.array_equal(got, want):
         print("MISMATCH", dict(ratio=ratio, algo=algo, w=w, h=h, stride=stride, bottom_up=bottom_up, kind=kind, mode=mode),
-              len(got), len(want), flush=True)
+              len(got), len(want), getattr(chain_scan, "last", None) if mode == 5 else "", flush=True)
+        # the case, for a closer look: rows, what came out, what was expected
+        np.savez_compressed(os.path.join(ROOT, "gpurun_out", "fuzz_mismatch.npz"), rows=rows, got=got, want=want,
+                            params=np.array([w, h, stride, int(bottom_up), kind, mode, *ratio]))
         sys.exit(1)
     done += 1
     fused += int(enc.fused_coding())
