@@ -29,7 +29,7 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contra
              "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 HIP_SOURCES = ["front.hip", "coded.hip", "staged.hip", "entropy.hip", "api.hip", "static.hip", "chain.hip"]
-HIP_HEADERS = ["internal.hpp", "transform.hpp", "tile.hpp", "coding.hpp", "tables.h", os.path.join(ROOT, "include", "jpeg_hip.h")]
+HIP_HEADERS = ["internal.hpp", "transform.hpp", "tile.hpp", "coding.hpp", "chain.hpp", "tables.h", os.path.join(ROOT, "include", "jpeg_hip.h")]
 LIB_HIP = os.path.join(HERE, "libjpeg_hip.so")
 
 HOST_SOURCES = ["host/bmp.cpp", "host/jfif.cpp", "host/stripes.cpp"]

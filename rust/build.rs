@@ -8,7 +8,7 @@ use std::env;
 use std::path::{Path, PathBuf};
 use std::process::Command;
 
-const HIP_SOURCES: [&str; 6] = ["front.hip", "coded.hip", "staged.hip", "entropy.hip", "api.hip", "static.hip"];
+const HIP_SOURCES: [&str; 7] = ["front.hip", "coded.hip", "staged.hip", "entropy.hip", "api.hip", "static.hip", "chain.hip"];
 const HOST_SOURCES: [&str; 3] = ["host/bmp.cpp", "host/jfif.cpp", "host/stripes.cpp"];
 // the flags of jpeg-encoder_amd/build.py: the reference's f32 arithmetic is never fused, so contraction stays off
 const HIP_FLAGS: [&str; 8] = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
