@@ -40,13 +40,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 # the named configurations (index = position in the list of configurations the metric comes with, 1-based)
 CONFIGS = {
     1: dict(width=512, height=512, ratio="4:2:0", dct_algorithm="real-dct", mode="batch", resident=512, batch=8192,
-            per_launch=64),
+            per_launch=256),
     2: dict(width=3840, height=2160, ratio="4:4:4", dct_algorithm="bin-dct", mode="batch", resident=64, batch=640,
             per_launch=64),
     3: dict(width=7680, height=4320, ratio="4:2:0", dct_algorithm="real-dct", mode="batch", resident=64, batch=640,
             per_launch=64),
     4: dict(width=1920, height=1080, ratio="4:2:2", dct_algorithm="real-dct", mode="batch", resident=512, batch=4096,
-            per_launch=64),
+            per_launch=256),
     5: dict(width=32768, height=32768, ratio="4:2:0", dct_algorithm="real-dct", mode="stripes", passes=16),
 }
 

@@ -44,8 +44,8 @@ constexpr int STUFF_SEG = 4096;
 // words of the ticket counters of the stuffing kernel for a single image (a batch: two per image)
 constexpr int TICKET_WORDS_SINGLE = 64 + 64 * 64;
 // images one launch of the coding and stream kernels can take (jpg_max_batch): the pixel pointers of a launch
-// travel in the coding kernel's argument block
-constexpr int MAX_BATCH_IMAGES = 64;
+// travel in the coding kernel's argument block (2 KiB of its 4)
+constexpr int MAX_BATCH_IMAGES = 256;
 // groups of 64 chunks a stream reader can tabulate in LDS (52 KiB of LDS; limits an image to 27M blocks)
 constexpr int MAX_GROUPS = 6656;
 

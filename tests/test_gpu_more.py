@@ -409,7 +409,8 @@ def test_pipelined_encodes_keep_their_results(J, oracle, depth):
 
 
 @pytest.mark.parametrize("ratio,algo,w,h,n", [((4, 2, 2), "bin-dct", 320, 200, 7), ((4, 2, 0), "bin-dct", 1920, 1080, 16),
-                                             ((4, 4, 4), "real-dct-strict", 100, 60, 64), ((4, 2, 0), "bin-dct", 48, 40, 1)])
+                                             ((4, 4, 4), "real-dct-strict", 100, 60, 64), ((4, 2, 0), "bin-dct", 48, 40, 1),
+                                             ((4, 2, 0), "real-dct-strict", 512, 96, 256)])
 def test_batches_match_single_images(J, oracle, ratio, algo, w, h, n):
     """n equally sized images through one launch of each kernel: every image byte-exact; pipelined batches too."""
     import torch
@@ -431,7 +432,7 @@ def test_batches_match_single_images(J, oracle, ratio, algo, w, h, n):
     # a single image afterwards on the same context
     np.testing.assert_array_equal(enc.encode_scan(imgs[0], w, h), refs[0].stuffed_scan())
     with pytest.raises(J.JpgError):
-        enc.encode_batch_device_async(ptrs * 80, w, h, imgs[0].shape[1], True)  # more than jpg_max_batch
+        enc.encode_batch_device_async(ptrs * (enc.max_batch() // n + 1), w, h, imgs[0].shape[1], True)  # more than jpg_max_batch
 
 
 @pytest.mark.parametrize("ratio,algo,w,h", [
