@@ -894,25 +894,33 @@ __global__ __launch_bounds__(1024) void k_tail(const uint32_t *__restrict__ spar
     uint64_t sum = 0;
     const long long quads = (nchunks + 63) / 64 * 16;
     const uint4 *q = reinterpret_cast<const uint4 *>(clen);
-    for (long long i = tid; i - tid < quads; i += 1024) {      // (whole waves: the row sums below take all lanes)
-        uint4 v{0, 0, 0, 0};
-        if (i < quads) {
-            v = q[i];
+    constexpr int AHEAD = 4;                                     // loads in flight per thread: the kernel is one workgroup
+    for (long long i0 = tid; i0 - tid < quads; i0 += 1024 * AHEAD) {   // (whole waves: the row sums below take all lanes)
+        uint4 v[AHEAD];
+#pragma unroll
+        for (int k = 0; k < AHEAD; k++) {
+            const long long i = i0 + 1024 * k;
+            v[k] = uint4{0, 0, 0, 0};
+            if (i < quads) v[k] = q[i];
+        }
+#pragma unroll
+        for (int k = 0; k < AHEAD; k++) {
+            const long long i = i0 + 1024 * k;
             const long long c = i * 4;                           // (what lies behind the last chunk is not defined)
             if (c + 3 >= nchunks) {
-                if (c + 0 >= nchunks) v.x = 0;
-                if (c + 1 >= nchunks) v.y = 0;
-                if (c + 2 >= nchunks) v.z = 0;
-                v.w = 0;
+                if (c + 0 >= nchunks) v[k].x = 0;
+                if (c + 1 >= nchunks) v[k].y = 0;
+                if (c + 2 >= nchunks) v[k].z = 0;
+                v[k].w = 0;
             }
+            uint32_t part = v[k].x + v[k].y + v[k].z + v[k].w;
+            sum += part;
+            part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x111, 0xf, 0xf, false);   // row_shr:1
+            part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x112, 0xf, 0xf, false);   // row_shr:2
+            part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x114, 0xf, 0xf, false);   // row_shr:4
+            part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x118, 0xf, 0xf, false);   // row_shr:8
+            if (gsum && (tid & 15) == 15 && i < quads) gsum[i >> 4] = part;
         }
-        uint32_t part = v.x + v.y + v.z + v.w;
-        sum += part;
-        part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x111, 0xf, 0xf, false);   // row_shr:1
-        part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x112, 0xf, 0xf, false);   // row_shr:2
-        part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x114, 0xf, 0xf, false);   // row_shr:4
-        part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x118, 0xf, 0xf, false);   // row_shr:8
-        if (gsum && (tid & 15) == 15 && i < quads) gsum[i >> 4] = part;
     }
     sum = wave_sum64(sum);
     if (lane == 0) sSum[wave] = sum;
