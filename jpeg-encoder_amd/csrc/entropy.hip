@@ -61,7 +61,6 @@ __device__ __forceinline__ uint64_t hw_value(uint64_t w) { return w & ((1ull << 
 __device__ __forceinline__ void hw_store(uint64_t *p, uint64_t w) {
     __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void hw_store_plain(uint64_t *p, uint64_t w) { hw_store(p, w); }
 __device__ __forceinline__ uint64_t hw_load(const uint64_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -469,11 +468,10 @@ __attribute__((amdgpu_waves_per_eu(ST_THREADS == ST_THREADS_BATCH ? JPG_ST_WAVES
     __shared__ uint64_t sBefore[2];        // (in turn: two backs may follow each other with one barrier between them)
     __shared__ uint32_t sSeg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Stuffing: segments are handed out by a ticket counter, lowest first, so every segment with a lower
+    // Stuffing: segments are handed out by ticket counters, lowest first, so every segment with a lower
     // number than one a workgroup holds is held by a workgroup that is running (or has finished): the waits
     // below make progress however few workgroups are resident and whatever else runs on the device.  The
-    // ticket of the following round is fetched while the current segment is worked on, by a thread of the
-    // last wave, which loads nothing else in the first phases of a round (a wave's loads return in order).
+    // ticket of the following turn is drawn a turn ahead, by a thread of the last wave.
     const bool ticketer = tid == ST_THREADS - 1;
     uint32_t ticket = 0;
 #ifdef JPG_TRACE
@@ -560,7 +558,9 @@ __attribute__((amdgpu_waves_per_eu(ST_THREADS == ST_THREADS_BATCH ? JPG_ST_WAVES
     // draws a window of TEAM consecutive segments from the counter of the image and publishes it in the team's
     // record for the other TEAM - 1, who find their segment in it by the number they drew.  Windows are handed
     // to teams, and their segments to workgroups, in the order of the draws, by workgroups that are running:
-    // every segment below one that is held is held too, or is the next its team hands out.
+    // every segment below one that is held is held too, or is the next its team hands out.  The record keeps the
+    // windows of TEAM_RING rounds: a workgroup looks its window up a turn after it drew, and none gets more than a
+    // few turns ahead of the slowest (it would wait for that one's counts); a slot found overwritten is an error.
     uint32_t *const team_rec = a.ticket + TEAM_BASE + (wg / TEAM) * TEAM_WORDS;      // [0] the team's counter
     uint64_t *const team_win = reinterpret_cast<uint64_t *>(team_rec + 32);          // [TEAM_RING] {round + 1 : 32 | window : 32}
     uint32_t window = 0;
@@ -578,7 +578,7 @@ __attribute__((amdgpu_waves_per_eu(ST_THREADS == ST_THREADS_BATCH ? JPG_ST_WAVES
     auto draw_publish = [&]() {          // (waits for the window)
         if (!TEAMS || !ticketer || drawing != 2) return;
         if ((ticket & (TEAM - 1)) == 0)
-            hw_store_plain(&team_win[(ticket / TEAM) % TEAM_RING], ((uint64_t)(ticket / TEAM + 1) << 32) | window);
+            hw_store(&team_win[(ticket / TEAM) % TEAM_RING], ((uint64_t)(ticket / TEAM + 1) << 32) | window);
         drawing = 3;
     };
 
