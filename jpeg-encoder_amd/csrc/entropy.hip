@@ -346,6 +346,8 @@ struct StreamArgs {
     unsigned long long *trace;  // debug builds only
 };
 
+typedef uint16_t u16_unaligned __attribute__((aligned(1)));
+
 // number of 0xFF bytes in a word
 __device__ __forceinline__ uint32_t count_ff(uint32_t w) {
     const uint32_t z = ~w;
@@ -667,7 +669,7 @@ __attribute__((amdgpu_waves_per_eu(ST_THREADS == ST_THREADS_BATCH ? JPG_ST_WAVES
                 if (m < rounds && f < nwant) {
                     while (sW[i + 1] <= f) i++;
                     const int j = sW0[i] + (f - sW[i]);
-                    wv[m] = slots[(size_t)i * a.slot_words + j];
+                    wv[m] = slots[(uint32_t)i * (uint32_t)a.slot_words + (uint32_t)j];   // (256 slots: 32 bits do)
                     pos[m] = sT[i] + 32 * j;                      // where the word's first bit goes (>= -31)
                 }
                 f++;
@@ -744,9 +746,6 @@ __attribute__((amdgpu_waves_per_eu(ST_THREADS == ST_THREADS_BATCH ? JPG_ST_WAVES
     auto back = [&](const Held &hd, const Probe &probe) {
         const uint64_t seg = hd.seg;
         const uint32_t total = hd.total;
-        uint32_t c = 0;
-#pragma unroll
-        for (int k = 0; k < WPT; k++) c += count_ff(hd.t[k]);
         bool timeout = false;
         backs ^= 1;
         if (wave == 0) {
@@ -757,7 +756,10 @@ __attribute__((amdgpu_waves_per_eu(ST_THREADS == ST_THREADS_BATCH ? JPG_ST_WAVES
         if (__ballot(timeout) && lane == 0) raise_error(a.status, a.err_epoch, JPG_ERR_HIP);
         lds_barrier();
         JPG_STAMP(6);
-        const uint64_t before_segs = sBefore[backs];
+        // (the same in every lane: the address of the segment's output stays in scalar registers)
+        const uint64_t before_read = sBefore[backs];
+        const uint64_t before_segs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(before_read >> 32)) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)before_read);
         const uint64_t q = seg * SEG_WORDS + (uint64_t)WPT * tid;
         if (seg == nloop - 1 && tid == 0) {
             a.status->nbits = nbits;
@@ -773,18 +775,29 @@ __attribute__((amdgpu_waves_per_eu(ST_THREADS == ST_THREADS_BATCH ? JPG_ST_WAVES
             a.status->tail = tail;
             if (a.host_status) *a.host_status = *a.status;
         }
-        uint8_t *o = a.out + seg * STUFF_SEG + before_segs + 4 * WPT * tid + hd.before_in_seg;
-        if (4 * (q + WPT) <= nbytes && c == 0 && ((reinterpret_cast<uintptr_t>(o) & 3) == 0)) {
-            // common case: plain bytes, destination word-aligned
+        // Every byte but the thread's last is stored as two: itself and a zero behind it.  The next byte lands on that
+        // zero, or behind it when the byte was 0xFF (the stores of a lane are performed in order; two-byte stores
+        // need no alignment): no branch, no mask, and the destination needs no alignment either.
+        uint8_t *const ob = a.out + seg * STUFF_SEG + before_segs;
+        uint32_t off = 4 * WPT * tid + hd.before_in_seg;
+        if (4 * (q + WPT) <= nbytes) {
 #pragma unroll
-            for (int k = 0; k < WPT; k++) reinterpret_cast<uint32_t *>(o)[k] = __builtin_bswap32(hd.t[k]);
-        } else {
+            for (int k = 0; k < 4 * WPT - 1; k++) {
+                const uint32_t b = (hd.t[k >> 2] >> (24 - 8 * (k & 3))) & 0xffu;
+                *reinterpret_cast<u16_unaligned *>(ob + off) = (uint16_t)b;
+                off += 1 + (b == 0xffu);
+            }
+            const uint32_t b = hd.t[WPT - 1] & 0xffu;
+            ob[off] = (uint8_t)b;
+            if (b == 0xffu) ob[off + 1] = 0;
+        } else {                                                 // the last bytes of the stream
+            const uint32_t have = 4 * q < nbytes ? (uint32_t)(nbytes - 4 * q) : 0u;
 #pragma unroll
             for (int k = 0; k < 4 * WPT; k++) {
-                if (4 * q + k < nbytes) {
+                if ((uint32_t)k < have) {
                     const uint8_t b = (uint8_t)(hd.t[k >> 2] >> (24 - 8 * (k & 3)));
-                    *o++ = b;
-                    if (b == 0xff) *o++ = 0;
+                    ob[off++] = b;
+                    if (b == 0xff) ob[off++] = 0;
                 }
             }
         }
