@@ -109,6 +109,7 @@ struct jpg_ctx {
         ChainParams *h_params = nullptr;    // [2] copies of d_params, made at the end of a pass
         int last_of[2] = {0, 0};            // the last rank with a stripe in the pass: it publishes the scan's length
         int slot_of[2] = {0, 0};            // the context's set of back-end buffers the pass used
+        int queue_err[2] = {0, 0};          // status of the call that queued the pass
         DevStatus *h_status = nullptr;      // [2] status records of the passes
         hipEvent_t ev[2] = {nullptr, nullptr};   // end of a pass
         uint32_t epoch_of[2] = {0, 0};      // epoch the pass's errors are tagged with
@@ -1104,15 +1105,16 @@ extern "C" int jpg_chain_pass_async(jpg_ctx *c, uint64_t active_mask) {
     // pass, was measured and gains nothing -- the coding kernel slows down by what the stuffing takes.)
     const hipStream_t sa = c->stream, sb = c->stream;
     // the stripe's last DC coefficients (straight from its last MCU's pixels), published; the predecessor's fetched
-    HIP_TRY(c, launch_last_dc_pixels(c->g, c->algo, c->d_src, c->d_dc, sa, &cp));
+    hipError_t he = launch_last_dc_pixels(c->g, c->algo, c->d_src, c->d_dc, sa, &cp);
     sl.eb.chain = params;
     sl.eb.chain_slot = ch.mail + cp.slot * CHAIN_MAX_RANKS + ch.rank;
     sl.eb.chain_tag = cp.tag;
-    int e = launch_timed(c, 1, [&](hipEvent_t e0, hipEvent_t e1) {
-        return launch_coded(c->g, c->algo, c->d_src, nullptr, 1, ZERO_PRED, sl.eb, sa, e0, e1);
-    });
-    hipError_t he = hipSuccess;
-    if (!e) {
+    int e = JPG_OK;
+    if (he == hipSuccess)
+        e = launch_timed(c, 1, [&](hipEvent_t e0, hipEvent_t e1) {
+            return launch_coded(c->g, c->algo, c->d_src, nullptr, 1, ZERO_PRED, sl.eb, sa, e0, e1);
+        });
+    if (!e && he == hipSuccess) {
         he = launch_tail(sl.eb, sa);                           // bit count and last bits, published
         sl.tail_known = he == hipSuccess;
         if (he == hipSuccess) he = launch_chain_place(cp, sb);
@@ -1130,6 +1132,8 @@ extern "C" int jpg_chain_pass_async(jpg_ctx *c, uint64_t active_mask) {
     (void)hipEventRecord(sl.s_done, sb);
     sl.busy = true;
     (void)hipEventRecord(ch.ev[par], sb);
+    // (what jpg_chain_pass_finish reports for a pass that was not queued whole)
+    ch.queue_err[par] = e ? e : (he != hipSuccess ? JPG_ERR_HIP : JPG_OK);
     if (e) return e;
     HIP_TRY(c, he);
     return JPG_OK;
@@ -1147,6 +1151,7 @@ extern "C" int jpg_chain_pass_finish(jpg_ctx *c, uint64_t *nbits, size_t *piece_
     ch.taken++;
     jpg_ctx::Slot &sl = c->slot[ch.slot_of[par]];
     c->view = ch.slot_of[par];
+    if (ch.queue_err[par]) return ch.queue_err[par];
     const DevStatus &hs = ch.h_status[par];
     {
         const int v = -hs.error;
