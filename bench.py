@@ -277,6 +277,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Standard output carries one JSON line and nothing else: libraries that write there (gloo announces its
+    # connections on it) are sent to standard error until that line is printed.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     # rehearsal of the multi-process path on a box with one GPU: every rank on device 0, gloo for the barrier
     rehearsal = os.environ.get("BENCH_REHEARSAL_ONE_GPU") == "1"
 
@@ -630,7 +635,10 @@ def main():
                 out["e2e"] = e2e
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if stripes:
         if args.verify and rank == 0:
             whole = np.concatenate([synth_stripe(k)[:plan[k][1] - plan[k][0]] for k in reversed(range(world))])   # bottom-up file
